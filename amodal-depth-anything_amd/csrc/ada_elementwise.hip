@@ -1,0 +1,282 @@
+// HBM-bound kernels of the path: LayerNorm, patchify (im2col + ImageNet normalise), cls row, bilinear
+// resize (align_corners=True) with fused skip add.  See include/ada_hip.h for the reference call sites.
+// All of them move each byte once with 16-byte (fp32) / 8-byte (operand) accesses; row statistics use
+// wavefront shuffles only (one wave per row, no LDS).
+#include "ada_common.h"
+
+namespace {
+
+constexpr int LN_MAX_CHUNKS = 6;  // float4 chunks per lane: dim <= 6 * 64 * 4 = 1536
+
+ADA_DEV float wave_sum(float v) {
+    v += __shfl_xor(v, 32);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+ADA_DEV long pad_row(uint32_t m, int h, int w, FastDiv dW, FastDiv dHW) {
+    uint32_t b, rem, y, x;
+    fast_divmod(m, dHW, b, rem);
+    fast_divmod(rem, dW, y, x);
+    return ((long)b * (h + 2) + (y + 1)) * (w + 2) + (x + 1);
+}
+
+struct LnArgs {
+    const float* in;
+    long ld_in;
+    int rows_out, dim, group_in, skip;
+    FastDiv dGroupOut;
+    const float* weight;
+    const float* bias;
+    float eps;
+    op_t* out_op;
+    long ld_op;
+    int map_op, map_h, map_w;
+    FastDiv dMapW, dMapHW;
+    int relu;
+    float* out_f32;
+    long ld_f32;
+};
+
+__global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int ro = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ro >= p.rows_out) return;
+    long in_row = ro;
+    if (p.group_in > 0) {
+        uint32_t g, w;
+        fast_divmod((uint32_t)ro, p.dGroupOut, g, w);
+        in_row = (long)g * p.group_in + p.skip + w;
+    }
+    const float4* src = (const float4*)(p.in + in_row * p.ld_in);
+    const int nchunk = p.dim >> 2;
+    float4 v[LN_MAX_CHUNKS];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            v[i] = src[c];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = wave_sum(s) / (float)p.dim;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.dim + p.eps);
+    long orow = ro;
+    if (p.out_op && p.map_op == ADA_MAP_PAD) orow = pad_row((uint32_t)ro, p.map_h, p.map_w, p.dMapW, p.dMapHW);
+    const float4* w4 = (const float4*)p.weight;
+    const float4* b4 = (const float4*)p.bias;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            const float4 w = w4[c], bb = b4[c];
+            float4 y;
+            y.x = (v[i].x - mean) * rstd * w.x + bb.x;
+            y.y = (v[i].y - mean) * rstd * w.y + bb.y;
+            y.z = (v[i].z - mean) * rstd * w.z + bb.z;
+            y.w = (v[i].w - mean) * rstd * w.w + bb.w;
+            if (p.relu) {
+                y.x = __builtin_fmaxf(y.x, 0.f); y.y = __builtin_fmaxf(y.y, 0.f);
+                y.z = __builtin_fmaxf(y.z, 0.f); y.w = __builtin_fmaxf(y.w, 0.f);
+            }
+            if (p.out_f32) ((float4*)(p.out_f32 + (long)ro * p.ld_f32))[c] = y;
+            if (p.out_op) {
+                opx4 o;
+                o[0] = to_op(y.x); o[1] = to_op(y.y); o[2] = to_op(y.z); o[3] = to_op(y.w);
+                ((opx4*)(p.out_op + orow * p.ld_op))[c] = o;
+            }
+        }
+    }
+}
+
+// one workgroup per patch row; a thread handles column pairs (dx, dx+1) of the same (c, dy)
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, const float* __restrict__ guide, int cg,
+                                                       int H, int W, int ph, int pw, float3 mean, float3 inv_std, int normalise,
+                                                       op_t* __restrict__ out, long ld) {
+    const int p = blockIdx.x;  // (b, py, px)
+    const int px = p % pw;
+    const int py = (p / pw) % ph;
+    const int b = p / (pw * ph);
+    const int kreal = (3 + cg) * 196;
+    for (int pair = threadIdx.x; pair * 2 < ld; pair += blockDim.x) {
+        const int col = pair * 2;
+        float a0 = 0.f, a1 = 0.f;
+        if (col < kreal) {
+            const int c = col / 196;
+            const int rem = col - c * 196;
+            const int dy = rem / 14, dx = rem - dy * 14;
+            const long pix = (long)(py * 14 + dy) * W + px * 14 + dx;
+            if (c < 3) {
+                const float2 v = *(const float2*)(x + ((long)b * 3 + c) * H * W + pix);
+                a0 = v.x; a1 = v.y;
+                if (normalise) {
+                    const float mu = c == 0 ? mean.x : (c == 1 ? mean.y : mean.z);
+                    const float is = c == 0 ? inv_std.x : (c == 1 ? inv_std.y : inv_std.z);
+                    a0 = (a0 - mu) * is;
+                    a1 = (a1 - mu) * is;
+                }
+            } else {
+                const float2 v = *(const float2*)(guide + ((long)b * cg + (c - 3)) * H * W + pix);
+                a0 = v.x; a1 = v.y;
+            }
+        }
+        opx2 o;
+        o[0] = to_op(a0);
+        o[1] = to_op(a1);
+        *(opx2*)(out + (long)p * ld + col) = o;
+    }
+}
+
+__global__ void write_cls_kernel(float* tokens, int batch, int n_tok, int dim, const float* cls, const float* pos0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * dim) return;
+    const int b = i / dim, d = i - b * dim;
+    tokens[(long)b * n_tok * dim + d] = cls[d] + pos0[d];
+}
+
+struct BilinearArgs {
+    const float* in;
+    long ld_in;
+    int batch, hi, wi, ho, wo, c4;  // c4 = channels / 4
+    float sy, sx;                   // (in-1)/(out-1), 0 when out == 1
+    const float* add;
+    long ld_add;
+    float* out_f32;
+    long ld_f32;
+    op_t* out_op;
+    long ld_op;
+    int map_op, relu;
+    FastDiv dC4, dWo, dHo;
+};
+
+__global__ __launch_bounds__(256) void bilinear_kernel(BilinearArgs p, long total) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    // gid = ((b*ho + y)*wo + x)*c4 + c ; decompose with 32-bit pieces (pixel count < 2^24 is checked on the host)
+    const uint32_t pix = (uint32_t)(gid / p.c4);
+    const int c = (int)(gid - (long)pix * p.c4);
+    uint32_t by, x, b, y;
+    fast_divmod(pix, p.dWo, by, x);
+    fast_divmod(by, p.dHo, b, y);
+    const float fy = p.sy * (float)y, fx = p.sx * (float)x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < p.hi - 1 ? 1 : 0), x1 = x0 + (x0 < p.wi - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
+    const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+    const long rb = (long)b * p.hi;
+    const float4 v00 = ((const float4*)(p.in + ((rb + y0) * p.wi + x0) * p.ld_in))[c];
+    const float4 v01 = ((const float4*)(p.in + ((rb + y0) * p.wi + x1) * p.ld_in))[c];
+    const float4 v10 = ((const float4*)(p.in + ((rb + y1) * p.wi + x0) * p.ld_in))[c];
+    const float4 v11 = ((const float4*)(p.in + ((rb + y1) * p.wi + x1) * p.ld_in))[c];
+    float4 r;
+    r.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+    r.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+    r.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+    r.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+    if (p.add) {
+        const float4 a = ((const float4*)(p.add + (long)pix * p.ld_add))[c];
+        r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
+    }
+    if (p.out_f32) ((float4*)(p.out_f32 + (long)pix * p.ld_f32))[c] = r;
+    if (p.out_op) {
+        long orow = pix;
+        if (p.map_op == ADA_MAP_PAD) orow = ((long)b * (p.ho + 2) + (y + 1)) * (p.wo + 2) + (x + 1);
+        opx4 o;
+        if (p.relu) {
+            r.x = __builtin_fmaxf(r.x, 0.f); r.y = __builtin_fmaxf(r.y, 0.f);
+            r.z = __builtin_fmaxf(r.z, 0.f); r.w = __builtin_fmaxf(r.w, 0.f);
+        }
+        o[0] = to_op(r.x); o[1] = to_op(r.y); o[2] = to_op(r.z); o[3] = to_op(r.w);
+        ((opx4*)(p.out_op + orow * p.ld_op))[c] = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int ada_layernorm_fwd(const float* in, int64_t ld_in, int32_t rows_out, int32_t dim, int32_t group_in, int32_t skip,
+                                 const float* weight, const float* bias, float eps, void* out_op, int64_t ld_op, int32_t map_op,
+                                 int32_t map_h, int32_t map_w, int32_t relu, float* out_f32, int64_t ld_f32, void* stream) {
+    ADA_REQUIRE(in && weight && bias, ADA_EINVAL, "ada_layernorm_fwd: null pointer");
+    ADA_REQUIRE(out_op || out_f32, ADA_EINVAL, "ada_layernorm_fwd: no output buffer");
+    ADA_REQUIRE(rows_out > 0 && dim > 0, ADA_EINVAL, "ada_layernorm_fwd: bad shape rows=%d dim=%d", rows_out, dim);
+    ADA_REQUIRE(dim % 4 == 0 && dim <= LN_MAX_CHUNKS * 256, ADA_EUNSUPPORTED, "ada_layernorm_fwd: dim=%d must be a multiple of 4 and <= 1536", dim);
+    ADA_REQUIRE(ld_in % 4 == 0 && (!out_f32 || ld_f32 % 4 == 0) && (!out_op || ld_op % 4 == 0), ADA_EINVAL, "ada_layernorm_fwd: leading dims must be multiples of 4");
+    ADA_REQUIRE(group_in == 0 || (skip >= 0 && skip < group_in), ADA_EINVAL, "ada_layernorm_fwd: bad group/skip");
+    ADA_REQUIRE(map_op == ADA_MAP_PLAIN || map_op == ADA_MAP_PAD, ADA_EUNSUPPORTED, "ada_layernorm_fwd: map must be PLAIN or PAD");
+    if (out_op && map_op == ADA_MAP_PAD) ADA_REQUIRE(map_h > 0 && map_w > 0 && rows_out % (map_h * map_w) == 0, ADA_EINVAL, "ada_layernorm_fwd: bad PAD grid");
+    ADA_REQUIRE((long)rows_out < (1L << 24), ADA_EUNSUPPORTED, "ada_layernorm_fwd: too many rows");
+    LnArgs p;
+    p.in = in; p.ld_in = ld_in; p.rows_out = rows_out; p.dim = dim; p.group_in = group_in; p.skip = skip;
+    p.dGroupOut = make_fastdiv(group_in > 0 ? group_in - skip : 1);
+    p.weight = weight; p.bias = bias; p.eps = eps;
+    p.out_op = (op_t*)out_op; p.ld_op = ld_op; p.map_op = map_op; p.map_h = map_h; p.map_w = map_w;
+    p.dMapW = make_fastdiv(map_w > 0 ? map_w : 1);
+    p.dMapHW = make_fastdiv(map_h > 0 && map_w > 0 ? map_h * map_w : 1);
+    p.relu = relu; p.out_f32 = out_f32; p.ld_f32 = ld_f32;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows_out + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    return ada_check_launch("ada_layernorm_fwd");
+}
+
+extern "C" int ada_patchify(const float* x, const float* guide, int32_t batch, int32_t cg, int32_t height, int32_t width,
+                            const float* mean, const float* inv_std, void* out, int64_t ld, void* stream) {
+    ADA_REQUIRE(x && out, ADA_EINVAL, "ada_patchify: null pointer");
+    ADA_REQUIRE(cg == 0 || guide, ADA_EINVAL, "ada_patchify: guide channels without guide tensor");
+    ADA_REQUIRE(batch > 0 && cg >= 0 && height > 0 && width > 0, ADA_EINVAL, "ada_patchify: bad shape");
+    ADA_REQUIRE(height % 14 == 0 && width % 14 == 0, ADA_EINVAL, "ada_patchify: %dx%d is not a multiple of the 14-pixel patch", height, width);
+    ADA_REQUIRE(ld % 2 == 0 && ld >= (3 + cg) * 196, ADA_EINVAL, "ada_patchify: ld=%ld too small", (long)ld);
+    ADA_REQUIRE((mean == nullptr) == (inv_std == nullptr), ADA_EINVAL, "ada_patchify: mean and inv_std go together");
+    float3 mu = make_float3(0.f, 0.f, 0.f), is = make_float3(1.f, 1.f, 1.f);
+    if (mean) {  // host pointers: three floats each
+        mu = make_float3(mean[0], mean[1], mean[2]);
+        is = make_float3(inv_std[0], inv_std[1], inv_std[2]);
+    }
+    const int ph = height / 14, pw = width / 14;
+    hipLaunchKernelGGL(patchify_kernel, dim3(batch * ph * pw), dim3(256), 0, (hipStream_t)stream, x, guide, cg, height, width, ph, pw,
+                       mu, is, mean ? 1 : 0, (op_t*)out, (long)ld);
+    return ada_check_launch("ada_patchify");
+}
+
+extern "C" int ada_write_cls(float* tokens, int32_t batch, int32_t n_tokens, int32_t dim, const float* cls, const float* pos0, void* stream) {
+    ADA_REQUIRE(tokens && cls && pos0, ADA_EINVAL, "ada_write_cls: null pointer");
+    ADA_REQUIRE(batch > 0 && n_tokens > 0 && dim > 0, ADA_EINVAL, "ada_write_cls: bad shape");
+    const int total = batch * dim;
+    hipLaunchKernelGGL(write_cls_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, tokens, batch, n_tokens, dim, cls, pos0);
+    return ada_check_launch("ada_write_cls");
+}
+
+extern "C" int ada_bilinear_fwd(const float* in, int64_t ld_in, int32_t batch, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                                int32_t channels, const float* add, int64_t ld_add, float* out_f32, int64_t ld_f32, void* out_op,
+                                int64_t ld_op, int32_t map_op, int32_t relu, void* stream) {
+    ADA_REQUIRE(in && (out_f32 || out_op), ADA_EINVAL, "ada_bilinear_fwd: null pointer");
+    ADA_REQUIRE(batch > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0 && channels > 0, ADA_EINVAL, "ada_bilinear_fwd: bad shape");
+    ADA_REQUIRE(channels % 4 == 0 && ld_in % 4 == 0 && (!add || ld_add % 4 == 0) && (!out_f32 || ld_f32 % 4 == 0) && (!out_op || ld_op % 4 == 0),
+                ADA_EINVAL, "ada_bilinear_fwd: channels and leading dims must be multiples of 4");
+    ADA_REQUIRE(map_op == ADA_MAP_PLAIN || map_op == ADA_MAP_PAD, ADA_EUNSUPPORTED, "ada_bilinear_fwd: map must be PLAIN or PAD");
+    ADA_REQUIRE((long)batch * ho * wo < (1L << 24), ADA_EUNSUPPORTED, "ada_bilinear_fwd: more than 2^24 output pixels");
+    BilinearArgs p;
+    p.in = in; p.ld_in = ld_in; p.batch = batch; p.hi = hi; p.wi = wi; p.ho = ho; p.wo = wo; p.c4 = channels / 4;
+    p.sy = ho > 1 ? (float)(hi - 1) / (float)(ho - 1) : 0.0f;
+    p.sx = wo > 1 ? (float)(wi - 1) / (float)(wo - 1) : 0.0f;
+    p.add = add; p.ld_add = ld_add; p.out_f32 = out_f32; p.ld_f32 = ld_f32; p.out_op = (op_t*)out_op; p.ld_op = ld_op;
+    p.map_op = map_op; p.relu = relu;
+    p.dC4 = make_fastdiv(p.c4); p.dWo = make_fastdiv(wo); p.dHo = make_fastdiv(ho);
+    const long total = (long)batch * ho * wo * p.c4;
+    hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, total);
+    return ada_check_launch("ada_bilinear_fwd");
+}

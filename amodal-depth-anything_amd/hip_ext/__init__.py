@@ -1,0 +1,238 @@
+"""hip_ext -- ctypes binding of libada_hip.so (the C ABI declared in include/ada_hip.h).
+
+PyTorch is used here for device memory and streams only: every wrapper hands raw device pointers,
+sizes and the current HIP stream to the library.  There is NO fallback: if the shared library is
+missing or a tensor is not on a HIP device the call raises -- the product path never computes on
+the CPU (the fp32 CPU oracle under /oracle is test infrastructure and is never imported here).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+
+# --- constants mirrored from include/ada_hip.h ------------------------------------------------
+ABI_VERSION = 1
+DT_F32, DT_F16, DT_BF16 = 0, 1, 2
+A_PLAIN, A_CONV3 = 0, 1
+MAP_PLAIN, MAP_PAD, MAP_TOKEN, MAP_SHUFFLE = 0, 1, 2, 3
+EP_BIAS, EP_GELU, EP_GAMMA, EP_RESIDUAL, EP_RELU_OP, EP_SWIGLU, EP_TAIL, EP_RELU_F32 = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40, 0x80
+ACT_NONE, ACT_SIGMOID, ACT_RELU = 0, 1, 2
+
+EXPORTS = (
+    "ada_abi_version", "ada_operand_dtype", "ada_last_error", "ada_igemm", "ada_attention_fwd",
+    "ada_layernorm_fwd", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
+)
+
+
+class IgemmArgs(ctypes.Structure):
+    """struct ada_igemm_args (include/ada_hip.h) -- field order and types must match exactly."""
+    _fields_ = [
+        ("M", c_int32), ("N", c_int32), ("K", c_int32), ("a_mode", c_int32),
+        ("A", c_void_p), ("lda", c_int64),
+        ("Ho", c_int32), ("Wo", c_int32), ("Hp", c_int32), ("Wp", c_int32), ("stride", c_int32),
+        ("W", c_void_p), ("bias", c_void_p), ("gamma", c_void_p), ("res", c_void_p), ("ldr", c_int64),
+        ("res_row_mod", c_int32), ("res_row_off", c_int32), ("flags", c_int32),
+        ("out_f32", c_void_p), ("ldo_f32", c_int64), ("map_f32", c_int32),
+        ("out_op", c_void_p), ("ldo_op", c_int64), ("map_op", c_int32),
+        ("map_h", c_int32), ("map_w", c_int32), ("shuffle_s", c_int32), ("shuffle_c", c_int32),
+        ("tail_w", c_void_p), ("tail_b", c_float), ("tail_act", c_int32),
+    ]
+
+
+class HipExtError(RuntimeError):
+    pass
+
+
+_lib = None
+_lib_path = None
+
+
+def library_path(bf16: bool = False) -> str:
+    return os.path.join(_CSRC, "libada_hip_bf16.so" if bf16 else "libada_hip.so")
+
+
+def load(path: Optional[str] = None):
+    """Loads (once) and returns the ctypes handle.  Raises HipExtError when the library is absent."""
+    global _lib, _lib_path
+    if _lib is not None and (path is None or path == _lib_path):
+        return _lib
+    path = path or os.environ.get("ADA_HIP_LIB") or library_path()
+    if not os.path.exists(path):
+        raise HipExtError(
+            f"libada_hip.so not found at {path}: build it with `python {os.path.join(_CSRC, 'build.py')}` "
+            "(there is no CPU fallback for the HIP path)")
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:  # pragma: no cover
+        raise HipExtError(f"cannot load {path}: {e}") from e
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise HipExtError(f"{path} does not export {name}")
+    lib.ada_abi_version.restype = c_int
+    lib.ada_operand_dtype.restype = c_int
+    lib.ada_last_error.restype = c_char_p
+    lib.ada_igemm.argtypes = [ctypes.POINTER(IgemmArgs), c_void_p]
+    lib.ada_igemm.restype = c_int
+    lib.ada_attention_fwd.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]
+    lib.ada_attention_fwd.restype = c_int
+    lib.ada_layernorm_fwd.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_float,
+                                      c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p]
+    lib.ada_layernorm_fwd.restype = c_int
+    lib.ada_patchify.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                 ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p, c_int64, c_void_p]
+    lib.ada_patchify.restype = c_int
+    lib.ada_write_cls.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
+    lib.ada_write_cls.restype = c_int
+    lib.ada_bilinear_fwd.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64,
+                                     c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p]
+    lib.ada_bilinear_fwd.restype = c_int
+    lib.ada_selftest.argtypes = [c_void_p, c_int64, c_void_p]
+    lib.ada_selftest.restype = c_int
+    if lib.ada_abi_version() != ABI_VERSION:
+        raise HipExtError(f"{path}: ABI version {lib.ada_abi_version()} != binding version {ABI_VERSION}")
+    _lib, _lib_path = lib, path
+    return lib
+
+
+def operand_dtype() -> torch.dtype:
+    """torch dtype of the contraction operands the loaded library was built for."""
+    return torch.float16 if load().ada_operand_dtype() == DT_F16 else torch.bfloat16
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load().ada_last_error().decode(errors="replace")
+        raise HipExtError(f"{what} failed (rc={rc}): {msg}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype=None) -> int:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise HipExtError(f"{name}: expected a tensor on a HIP device (the HIP path has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise HipExtError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _opt(t: Optional[torch.Tensor], name: str, dtype=None):
+    return None if t is None else _dev(t, name, dtype)
+
+
+class KernelTimer:
+    """Optional per-kernel timing with HIP events recorded on the stream the kernels are launched on
+    (bench.py uses it to compute the roofline fraction of the dominant kernels inside the timed region)."""
+
+    def __init__(self):
+        self.records = {}
+
+    def start(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def stop(self, name, ev0, work):
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record(torch.cuda.current_stream())
+        self.records.setdefault(name, []).append((ev0, ev1, float(work)))
+
+    def summary(self):
+        """name -> dict(launches, ms_total, ms_avg, work_total)  (call after a device synchronize)"""
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            out[name] = dict(launches=len(recs), ms_total=ms, ms_avg=ms / len(recs), work_total=sum(w for _, _, w in recs))
+        return out
+
+
+_timer: Optional[KernelTimer] = None
+
+
+def set_timer(t: Optional[KernelTimer]):
+    global _timer
+    _timer = t
+
+
+# ------------------------------------------------------------------------------------------------
+# thin wrappers (argument meaning = include/ada_hip.h)
+# ------------------------------------------------------------------------------------------------
+def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=None, gamma=None, res=None, ldr=0,
+          res_row_mod=0, res_row_off=0, flags=0, out_f32=None, ldo_f32=0, map_f32=MAP_PLAIN, out_op=None, ldo_op=0,
+          map_op=MAP_PLAIN, map_h=0, map_w=0, shuffle_s=0, shuffle_c=0, tail_w=None, tail_b=0.0, tail_act=ACT_NONE):
+    op = operand_dtype()
+    a = IgemmArgs()
+    a.M, a.N, a.K, a.a_mode = M, N, K, a_mode
+    a.A, a.lda = _dev(A, "A", op), lda
+    if conv is not None:
+        a.Ho, a.Wo, a.Hp, a.Wp, a.stride = conv
+    a.W = _dev(W, "W", op)
+    a.bias = _opt(bias, "bias", torch.float32)
+    a.gamma = _opt(gamma, "gamma", torch.float32)
+    a.res, a.ldr = _opt(res, "res", torch.float32), ldr
+    a.res_row_mod, a.res_row_off, a.flags = res_row_mod, res_row_off, flags
+    a.out_f32, a.ldo_f32, a.map_f32 = _opt(out_f32, "out_f32", torch.float32), ldo_f32, map_f32
+    a.out_op, a.ldo_op, a.map_op = _opt(out_op, "out_op", op), ldo_op, map_op
+    a.map_h, a.map_w, a.shuffle_s, a.shuffle_c = map_h, map_w, shuffle_s, shuffle_c
+    a.tail_w, a.tail_b, a.tail_act = _opt(tail_w, "tail_w", torch.float32), tail_b, tail_act
+    if _timer is not None:
+        ev = _timer.start()
+        _check(load().ada_igemm(ctypes.byref(a), _stream()), "ada_igemm")
+        _timer.stop("igemm", ev, 2.0 * M * N * (k_alg if k_alg is not None else K))  # algorithmic FLOP (MAC = 2)
+        return
+    _check(load().ada_igemm(ctypes.byref(a), _stream()), "ada_igemm")
+
+
+def attention(qkv: torch.Tensor, out: torch.Tensor, batch: int, n_tokens: int, heads: int):
+    op = operand_dtype()
+    ev = _timer.start() if _timer is not None else None
+    _check(load().ada_attention_fwd(_dev(qkv, "qkv", op), _dev(out, "out", op), batch, n_tokens, heads, _stream()),
+           "ada_attention_fwd")
+    if ev is not None:
+        _timer.stop("attention", ev, 4.0 * batch * heads * 64 * float(n_tokens) ** 2)  # QK^T + PV, MAC = 2
+
+
+def layernorm(inp, ld_in, rows_out, dim, weight, bias, eps, *, group_in=0, skip=0, out_op=None, ld_op=0, map_op=MAP_PLAIN,
+              map_h=0, map_w=0, relu=False, out_f32=None, ld_f32=0):
+    op = operand_dtype()
+    _check(load().ada_layernorm_fwd(_dev(inp, "in", torch.float32), ld_in, rows_out, dim, group_in, skip,
+                                    _dev(weight, "weight", torch.float32), _dev(bias, "bias", torch.float32), eps,
+                                    _opt(out_op, "out_op", op), ld_op, map_op, map_h, map_w, int(relu),
+                                    _opt(out_f32, "out_f32", torch.float32), ld_f32, _stream()), "ada_layernorm_fwd")
+
+
+def patchify(x, guide, batch, cg, height, width, mean, inv_std, out, ld):
+    op = operand_dtype()
+    if mean is not None:
+        m = (c_float * 3)(*mean)
+        s = (c_float * 3)(*inv_std)
+    else:
+        m = s = None
+    _check(load().ada_patchify(_dev(x, "x", torch.float32), _opt(guide, "guide", torch.float32), batch, cg, height, width,
+                               m, s, _dev(out, "out", op), ld, _stream()), "ada_patchify")
+
+
+def write_cls(tokens, batch, n_tokens, dim, cls, pos0):
+    _check(load().ada_write_cls(_dev(tokens, "tokens", torch.float32), batch, n_tokens, dim,
+                                _dev(cls, "cls", torch.float32), _dev(pos0, "pos0", torch.float32), _stream()), "ada_write_cls")
+
+
+def bilinear(inp, ld_in, batch, hi, wi, ho, wo, channels, *, add=None, ld_add=0, out_f32=None, ld_f32=0, out_op=None,
+             ld_op=0, map_op=MAP_PLAIN, relu=False):
+    op = operand_dtype()
+    _check(load().ada_bilinear_fwd(_dev(inp, "in", torch.float32), ld_in, batch, hi, wi, ho, wo, channels,
+                                   _opt(add, "add", torch.float32), ld_add, _opt(out_f32, "out_f32", torch.float32), ld_f32,
+                                   _opt(out_op, "out_op", op), ld_op, map_op, int(relu), _stream()), "ada_bilinear_fwd")
+
+
+def selftest() -> int:
+    scratch = torch.zeros(1 << 18, dtype=torch.int32, device="cuda")
+    return load().ada_selftest(scratch.data_ptr(), scratch.numel() * 4, _stream())

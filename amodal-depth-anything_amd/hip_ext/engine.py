@@ -1,0 +1,382 @@
+"""Forward engine: runs the whole Depth-Anything-V2 / Amodal-DAv2 forward pass as a fixed sequence of
+libada_hip launches on the current HIP stream.
+
+The nn.Module tree in ``src/models`` owns the fp32 parameters (reference ``state_dict`` schema); this
+engine owns everything derived from them:
+
+* ``PackedWeights`` -- operand-typed, MFMA-friendly copies made once per parameter version: linear /
+  1x1 weights as [N, K]; 3x3 weights as [N, 9*Cp] (tap-major, channels padded to 64); transposed-conv
+  weights as [s*s*Cout, Cin] with the bias expanded; the RGB and guidance patch-embed filters fused
+  into one [D, 1024] matrix (reference DA2/dinov2.py:237-240 adds the two embeddings, so one GEMM over
+  the concatenated K does both); the q rows of qkv pre-multiplied by head_dim**-0.5 = 2**-3 (exact).
+* ``Workspace`` -- every activation buffer for a (batch, H, W), allocated once and kept resident in HBM.
+
+Data layout: the residual stream is fp32 [B*N, D]; every tensor that is only ever a contraction
+operand is stored in the operand type (fp16 by default); DPT-head activations are NHWC, 3x3-conv
+inputs carry a one-pixel zero border so the implicit-GEMM gather never branches.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import (A_CONV3, A_PLAIN, ACT_NONE, ACT_RELU, ACT_SIGMOID, EP_BIAS, EP_GAMMA, EP_GELU, EP_RELU_OP, EP_RESIDUAL,
+               EP_SWIGLU, EP_TAIL, MAP_PAD, MAP_PLAIN, MAP_SHUFFLE, MAP_TOKEN, HipExtError)
+from . import attention as k_attention
+from . import bilinear as k_bilinear
+from . import igemm as k_igemm
+from . import layernorm as k_layernorm
+from . import operand_dtype
+from . import patchify as k_patchify
+from . import write_cls as k_write_cls
+
+PATCH = 14
+LN_EPS = 1e-6
+VIT = {
+    "vits": dict(dim=384, depth=12, heads=6, ffn="mlp"),
+    "vitb": dict(dim=768, depth=12, heads=12, ffn="mlp"),
+    "vitl": dict(dim=1024, depth=24, heads=16, ffn="mlp"),
+    "vitg": dict(dim=1536, depth=40, heads=24, ffn="swiglu"),
+}
+TAPS = {"vits": [2, 5, 8, 11], "vitb": [2, 5, 8, 11], "vitl": [4, 11, 17, 23], "vitg": [9, 19, 29, 39]}
+MAX_ROWS = (1 << 24) - 1  # row-index limit of the kernels' fast division
+
+
+def _r64(c: int) -> int:
+    return (c + 63) // 64 * 64
+
+
+class PackedWeights:
+    """Operand-typed copies of the parameters, laid out for the kernels.  ``sd``: name -> fp32 CUDA tensor
+    with the *raw* model's key names (``pretrained.*``, ``depth_head.*``)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], encoder: str, guided: bool, amodal_head: bool):
+        op = operand_dtype()
+        cfg = VIT[encoder]
+        D = cfg["dim"]
+        self.encoder, self.guided, self.amodal_head = encoder, guided, amodal_head
+        self.dim, self.depth, self.heads, self.ffn = D, cfg["depth"], cfg["heads"], cfg["ffn"]
+
+        def f32(name):
+            return sd[name].detach().to(torch.float32).contiguous()
+
+        def lin(w):  # [N, K] -> operand type, K padded to 64
+            w = w.reshape(w.shape[0], -1)
+            k = w.shape[1]
+            if k % 64:
+                w = F.pad(w, (0, _r64(k) - k))
+            return w.to(op).contiguous()
+
+        def conv3(w):  # [Co, Ci, 3, 3] -> [Co, 9 * Cip], tap-major
+            co, ci = w.shape[:2]
+            w = w.permute(0, 2, 3, 1)
+            if ci % 64:
+                w = F.pad(w, (0, _r64(ci) - ci))
+            return w.reshape(co, -1).to(op).contiguous()
+
+        def convT(w, b, s):  # [Ci, Co, s, s] -> [s*s*Co, Cip], bias expanded to [s*s*Co]
+            ci, co = w.shape[:2]
+            wt = w.permute(2, 3, 1, 0).reshape(s * s * co, ci)
+            return lin(wt), b.repeat(s * s).contiguous()
+
+        p = "pretrained."
+        w_rgb = f32(p + "patch_embed.proj.weight").reshape(D, -1)
+        b_pe = f32(p + "patch_embed.proj.bias")
+        self.guide_channels = 0
+        if guided:
+            w_g = f32(p + "patch_embed_guidance.proj.weight")
+            self.guide_channels = w_g.shape[1]
+            w_rgb = torch.cat([w_rgb, w_g.reshape(D, -1)], dim=1)
+            b_pe = b_pe + f32(p + "patch_embed_guidance.proj.bias")
+        self.pe_w, self.pe_b = lin(w_rgb), b_pe.contiguous()
+        self.pe_k = self.pe_w.shape[1]
+        self.cls = f32(p + "cls_token").reshape(D)
+        self.pos_native = f32(p + "pos_embed")  # [1, 1 + 37*37, D]
+        self._pos_cache: Dict[tuple, torch.Tensor] = {}
+
+        self.blocks = []
+        for i in range(self.depth):
+            b = f"{p}blocks.{i}."
+            qw, qb = f32(b + "attn.qkv.weight").clone(), f32(b + "attn.qkv.bias").clone()
+            qw[:D] *= 0.125  # head_dim ** -0.5 with head_dim = 64 (reference attention.py:41,53): exact in any binary format
+            qb[:D] *= 0.125
+            blk = dict(
+                ln1_w=f32(b + "norm1.weight"), ln1_b=f32(b + "norm1.bias"),
+                qkv_w=lin(qw), qkv_b=qb,
+                proj_w=lin(f32(b + "attn.proj.weight")), proj_b=f32(b + "attn.proj.bias"), ls1=f32(b + "ls1.gamma"),
+                ln2_w=f32(b + "norm2.weight"), ln2_b=f32(b + "norm2.bias"), ls2=f32(b + "ls2.gamma"),
+            )
+            if self.ffn == "mlp":
+                blk.update(fc1_w=lin(f32(b + "mlp.fc1.weight")), fc1_b=f32(b + "mlp.fc1.bias"),
+                           fc2_w=lin(f32(b + "mlp.fc2.weight")), fc2_b=f32(b + "mlp.fc2.bias"))
+                blk["hidden"] = blk["fc1_w"].shape[0]
+            else:
+                w12, b12 = f32(b + "mlp.w12.weight"), f32(b + "mlp.w12.bias")
+                hid = w12.shape[0] // 2
+                assert hid % 32 == 0
+                # interleave x1 / x2 rows in groups of 32 so one wave's two MFMA column tiles hold the gate pair
+                idx = torch.arange(hid, device=w12.device).reshape(-1, 32)
+                order = torch.stack([idx, idx + hid], dim=1).reshape(-1)
+                blk.update(w12_w=lin(w12[order]), w12_b=b12[order].contiguous(),
+                           w3_w=lin(f32(b + "mlp.w3.weight")), w3_b=f32(b + "mlp.w3.bias"))
+                blk["hidden"] = hid
+            self.blocks.append(blk)
+        self.norm_w, self.norm_b = f32(p + "norm.weight"), f32(p + "norm.bias")
+
+        h = "depth_head."
+        self.oc = [sd[f"{h}projects.{i}.weight"].shape[0] for i in range(4)]
+        self.features = sd[h + "scratch.layer1_rn.weight"].shape[0]
+        self.proj_w = [lin(f32(f"{h}projects.{i}.weight")) for i in range(4)]
+        self.proj_b = [f32(f"{h}projects.{i}.bias") for i in range(4)]
+        self.rs0_w, self.rs0_b = convT(f32(h + "resize_layers.0.weight"), f32(h + "resize_layers.0.bias"), 4)
+        self.rs1_w, self.rs1_b = convT(f32(h + "resize_layers.1.weight"), f32(h + "resize_layers.1.bias"), 2)
+        self.rs3_w, self.rs3_b = conv3(f32(h + "resize_layers.3.weight")), f32(h + "resize_layers.3.bias")
+        if amodal_head:
+            self.ip_w = [conv3(f32(f"{h}input_projection.{i}.0.weight")) for i in range(4)]
+            self.ip_b = [f32(f"{h}input_projection.{i}.0.bias") for i in range(4)]
+            self.ip_ln_w = [f32(f"{h}input_projection.{i}.1.weight") for i in range(4)]
+            self.ip_ln_b = [f32(f"{h}input_projection.{i}.1.bias") for i in range(4)]
+        s = h + "scratch."
+        self.rn_w = [conv3(f32(f"{s}layer{i + 1}_rn.weight")) for i in range(4)]
+        self.fuse = []
+        for k in range(1, 5):
+            r = f"{s}refinenet{k}."
+            d = dict(out_w=lin(f32(r + "out_conv.weight")), out_b=f32(r + "out_conv.bias"))
+            for u in (1, 2):
+                for c in (1, 2):
+                    d[f"u{u}c{c}_w"] = conv3(f32(f"{r}resConfUnit{u}.conv{c}.weight"))
+                    d[f"u{u}c{c}_b"] = f32(f"{r}resConfUnit{u}.conv{c}.bias")
+            self.fuse.append(d)  # index k-1
+        self.oc1_w, self.oc1_b = conv3(f32(s + "output_conv1.weight")), f32(s + "output_conv1.bias")
+        self.oc2_w, self.oc2_b = conv3(f32(s + "output_conv2.0.weight")), f32(s + "output_conv2.0.bias")
+        self.tail_w = f32(s + "output_conv2.2.weight").reshape(-1).contiguous()
+        self.tail_b = float(f32(s + "output_conv2.2.bias").reshape(-1)[0].item())
+
+    def pos_embed(self, ph: int, pw: int) -> torch.Tensor:
+        """[1 + ph*pw, D] fp32 position table for a ph x pw patch grid (reference DA2/dinov2.py:199-230).
+        The native 37x37 square grid is used as is; anything else is a one-off bicubic resample of the
+        parameter (cached per grid) -- a parameter transform like weight packing, not part of the per-image path."""
+        key = (ph, pw)
+        if key in self._pos_cache:
+            return self._pos_cache[key]
+        pos = self.pos_native
+        n = pos.shape[1] - 1
+        if not (ph * pw == n and ph == pw):
+            sq = int(math.sqrt(n))
+            # reference quirk kept on purpose: w0 is derived from x.shape[2] (image *height*) -- dinov2.py:233,209
+            w0, h0 = ph + 0.1, pw + 0.1
+            grid = pos[:, 1:].reshape(1, sq, sq, -1).permute(0, 3, 1, 2)
+            grid = F.interpolate(grid, scale_factor=(float(w0) / sq, float(h0) / sq), mode="bicubic", antialias=False)
+            assert grid.shape[-2] == ph and grid.shape[-1] == pw
+            pos = torch.cat([pos[:, :1], grid.permute(0, 2, 3, 1).reshape(1, ph * pw, -1)], dim=1)
+        out = pos[0].contiguous()
+        self._pos_cache[key] = out
+        return out
+
+
+class Workspace:
+    def __init__(self, pw_: PackedWeights, B: int, H: int, W: int, device):
+        op = operand_dtype()
+        self.B, self.H, self.W = B, H, W
+        ph, pw = H // PATCH, W // PATCH
+        self.ph, self.pw = ph, pw
+        Np = ph * pw
+        N = Np + 1
+        D = pw_.dim
+        T, P = B * N, B * Np
+        Fch = pw_.features
+        Fp = _r64(Fch)
+
+        def z(*shape, dtype=op):
+            return torch.zeros(*shape, dtype=dtype, device=device)
+
+        self.a_pe = z(P, pw_.pe_k)
+        self.x = z(T, D, dtype=torch.float32)
+        self.y = z(T, D)
+        self.qkv = z(T, 3 * D)
+        self.o = z(T, D)
+        hidden = pw_.blocks[0]["hidden"]
+        self.hd = z(T, hidden)
+        self.taps = [z(P, D) for _ in range(4)]
+        # head grids
+        self.grid = [(4 * ph, 4 * pw), (2 * ph, 2 * pw), (ph, pw), ((ph - 1) // 2 + 1, (pw - 1) // 2 + 1)]
+        oc = pw_.oc
+        ocp = [_r64(c) for c in oc]
+        self.t0 = z(P, ocp[0])
+        self.t1 = z(P, ocp[1])
+        self.pre3 = z(B, ph + 2, pw + 2, ocp[3])
+        self.L = [z(B, g[0] + 2, g[1] + 2, ocp[i]) for i, g in enumerate(self.grid)]
+        if pw_.amodal_head:
+            self.ipf = [z(B * g[0] * g[1], oc[i], dtype=torch.float32) for i, g in enumerate(self.grid)]
+            self.L2 = [z(B, g[0] + 2, g[1] + 2, ocp[i]) for i, g in enumerate(self.grid)]
+        self.rnx = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
+        self.rnr = [z(B, g[0] + 2, g[1] + 2, Fp) for g in self.grid]
+        self.tmpa = [z(B, g[0] + 2, g[1] + 2, Fp) for g in self.grid]
+        self.r = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
+        self.s = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
+        self.sr = [z(B, g[0] + 2, g[1] + 2, Fp) for g in self.grid]
+        self.u = [z(B * g[0] * g[1], Fp) for g in self.grid]
+        self.zf = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
+        g0 = self.grid[0]
+        self.g296 = (2 * g0[0], 2 * g0[1])
+        self.p1 = z(B, self.g296[0] + 2, self.g296[1] + 2, Fp)
+        half = Fch // 2
+        self.half, self.halfp = half, _r64(half)
+        self.oc1 = z(B * self.g296[0] * self.g296[1], half, dtype=torch.float32)
+        self.fin = z(B, H + 2, W + 2, self.halfp)
+
+
+class DepthEngine:
+    """Runs one forward.  ``final_act``: 'sigmoid' | 'relu' | 'none'."""
+
+    def __init__(self, weights: PackedWeights, final_act: str, normalise_input: bool):
+        self.w = weights
+        self.final_act = {"sigmoid": ACT_SIGMOID, "relu": ACT_RELU, "none": ACT_NONE}[final_act]
+        self.normalise_input = normalise_input
+        self._ws: Dict[tuple, Workspace] = {}
+
+    def max_batch(self, H: int, W: int) -> int:
+        return max(1, MAX_ROWS // (H * W))
+
+    def workspace(self, B, H, W, device) -> Workspace:
+        key = (B, H, W, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = Workspace(self.w, B, H, W, device)
+            self._ws[key] = ws
+        return ws
+
+    # ---- small helpers over igemm ---------------------------------------------------------
+    @staticmethod
+    def _conv3(src_pad, w, M, N, grid, stride=1, cin=None, **kw):
+        B, Hp, Wp, Cp = src_pad.shape
+        k_igemm(M=M, N=N, K=9 * Cp, k_alg=9 * (cin or Cp), A=src_pad, lda=Cp, W=w, a_mode=A_CONV3,
+                conv=(grid[0], grid[1], Hp, Wp, stride), **kw)
+
+    def forward(self, x: torch.Tensor, guide: Optional[torch.Tensor]) -> torch.Tensor:
+        w = self.w
+        if not x.is_cuda:
+            raise HipExtError("DepthEngine.forward: input must live on a HIP device (no CPU fallback in the product path)")
+        B, C, H, W = x.shape
+        assert C == 3
+        assert H % PATCH == 0, f"Input image height {H} is not a multiple of patch height {PATCH}"
+        assert W % PATCH == 0, f"Input image width {W} is not a multiple of patch width: {PATCH}"
+        if w.guided:
+            if guide is None or guide.shape[1] != w.guide_channels:
+                raise HipExtError(f"guide tensor with {w.guide_channels} channels required")
+            guide = guide.contiguous().float()
+        x = x.contiguous().float()
+        ws = self.workspace(B, H, W, x.device)
+        D, heads = w.dim, w.heads
+        ph, pw = ws.ph, ws.pw
+        Np = ph * pw
+        N = Np + 1
+        T, P = B * N, B * Np
+
+        # ---- tokens: patchify (+normalise) -> one GEMM over [rgb | guide] -> + bias + pos, cls row ----------
+        mean = (0.485, 0.456, 0.406) if self.normalise_input else None
+        inv_std = (1 / 0.229, 1 / 0.224, 1 / 0.225) if self.normalise_input else None
+        k_patchify(x, guide if w.guided else None, B, w.guide_channels, H, W, mean, inv_std, ws.a_pe, w.pe_k)
+        pos = w.pos_embed(ph, pw)
+        k_igemm(M=P, N=D, K=w.pe_k, k_alg=(3 + w.guide_channels) * 196, A=ws.a_pe, lda=w.pe_k, W=w.pe_w, bias=w.pe_b, res=pos, ldr=D, res_row_mod=Np, res_row_off=1,
+                flags=EP_BIAS | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, map_f32=MAP_TOKEN, map_h=Np)
+        k_write_cls(ws.x, B, N, D, w.cls, pos)
+
+        # ---- transformer blocks ------------------------------------------------------------------
+        taps = TAPS[w.encoder]
+        for i, blk in enumerate(w.blocks):
+            k_layernorm(ws.x, D, T, D, blk["ln1_w"], blk["ln1_b"], LN_EPS, out_op=ws.y, ld_op=D)
+            k_igemm(M=T, N=3 * D, K=D, A=ws.y, lda=D, W=blk["qkv_w"], bias=blk["qkv_b"], flags=EP_BIAS, out_op=ws.qkv, ldo_op=3 * D)
+            k_attention(ws.qkv, ws.o, B, N, heads)
+            k_igemm(M=T, N=D, K=D, A=ws.o, lda=D, W=blk["proj_w"], bias=blk["proj_b"], gamma=blk["ls1"], res=ws.x, ldr=D,
+                    flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D)
+            k_layernorm(ws.x, D, T, D, blk["ln2_w"], blk["ln2_b"], LN_EPS, out_op=ws.y, ld_op=D)
+            hid = blk["hidden"]
+            if w.ffn == "mlp":
+                k_igemm(M=T, N=hid, K=D, A=ws.y, lda=D, W=blk["fc1_w"], bias=blk["fc1_b"], flags=EP_BIAS | EP_GELU,
+                        out_op=ws.hd, ldo_op=hid)
+                k_igemm(M=T, N=D, K=hid, A=ws.hd, lda=hid, W=blk["fc2_w"], bias=blk["fc2_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
+                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D)
+            else:
+                k_igemm(M=T, N=2 * hid, K=D, A=ws.y, lda=D, W=blk["w12_w"], bias=blk["w12_b"], flags=EP_BIAS | EP_SWIGLU,
+                        out_op=ws.hd, ldo_op=hid)
+                k_igemm(M=T, N=D, K=hid, A=ws.hd, lda=hid, W=blk["w3_w"], bias=blk["w3_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
+                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D)
+            if i in taps:  # shared final LayerNorm on the tap, cls row dropped (dinov2.py:337-340)
+                k_layernorm(ws.x, D, P, D, w.norm_w, w.norm_b, LN_EPS, group_in=N, skip=1, out_op=ws.taps[taps.index(i)], ld_op=D)
+
+        return self._head(ws, B)
+
+    def _head(self, ws: Workspace, B: int) -> torch.Tensor:
+        w = self.w
+        D = w.dim
+        ph, pw = ws.ph, ws.pw
+        P = B * ph * pw
+        oc = w.oc
+        Fch = w.features
+        grid = ws.grid
+        rows = [B * g[0] * g[1] for g in grid]
+
+        # ---- reassemble: 1x1 project + resize (dpt.py:171-173) -> zero-bordered NHWC operand tensors -----
+        k_igemm(M=P, N=oc[0], K=D, A=ws.taps[0], lda=D, W=w.proj_w[0], bias=w.proj_b[0], flags=EP_BIAS, out_op=ws.t0, ldo_op=ws.t0.shape[1])
+        k_igemm(M=P, N=16 * oc[0], K=ws.t0.shape[1], A=ws.t0, lda=ws.t0.shape[1], W=w.rs0_w, bias=w.rs0_b, flags=EP_BIAS,
+                out_op=ws.L[0], ldo_op=ws.L[0].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=4, shuffle_c=oc[0])
+        k_igemm(M=P, N=oc[1], K=D, A=ws.taps[1], lda=D, W=w.proj_w[1], bias=w.proj_b[1], flags=EP_BIAS, out_op=ws.t1, ldo_op=ws.t1.shape[1])
+        k_igemm(M=P, N=4 * oc[1], K=ws.t1.shape[1], A=ws.t1, lda=ws.t1.shape[1], W=w.rs1_w, bias=w.rs1_b, flags=EP_BIAS,
+                out_op=ws.L[1], ldo_op=ws.L[1].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=2, shuffle_c=oc[1])
+        k_igemm(M=P, N=oc[2], K=D, A=ws.taps[2], lda=D, W=w.proj_w[2], bias=w.proj_b[2], flags=EP_BIAS,
+                out_op=ws.L[2], ldo_op=ws.L[2].shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw)
+        k_igemm(M=P, N=oc[3], K=D, A=ws.taps[3], lda=D, W=w.proj_w[3], bias=w.proj_b[3], flags=EP_BIAS,
+                out_op=ws.pre3, ldo_op=ws.pre3.shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw)
+        self._conv3(ws.pre3, w.rs3_w, rows[3], oc[3], grid[3], stride=2, bias=w.rs3_b, flags=EP_BIAS,
+                    out_op=ws.L[3], ldo_op=ws.L[3].shape[3], map_op=MAP_PAD, map_h=grid[3][0], map_w=grid[3][1])
+
+        # ---- amodal only: input_projection = conv3x3 -> channels-first LN -> ReLU (dpt.py:153-159,178-179) ----
+        layers = ws.L
+        if w.amodal_head:
+            for i in range(4):
+                self._conv3(ws.L[i], w.ip_w[i], rows[i], oc[i], grid[i], bias=w.ip_b[i], flags=EP_BIAS, out_f32=ws.ipf[i], ldo_f32=oc[i])
+                k_layernorm(ws.ipf[i], oc[i], rows[i], oc[i], w.ip_ln_w[i], w.ip_ln_b[i], LN_EPS, out_op=ws.L2[i],
+                            ld_op=ws.L2[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], relu=True)
+            layers = ws.L2
+
+        # ---- layerN_rn (blocks.py:20-24): fp32 copy for the residual adds + ReLU'd operand copy for conv1 ----
+        for i in range(4):
+            self._conv3(layers[i], w.rn_w[i], rows[i], Fch, grid[i], flags=EP_RELU_OP, out_f32=ws.rnx[i], ldo_f32=Fch,
+                        out_op=ws.rnr[i], ldo_op=ws.rnr[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1])
+
+        def rcu(i, fw, unit, src_relu_pad, src_f32, **out):
+            """ResidualConvUnit (blocks.py:57-80) at grid i: conv2(relu(conv1(relu(x)))) + x."""
+            g = grid[i]
+            self._conv3(src_relu_pad, fw[f"u{unit}c1_w"], rows[i], Fch, g, bias=fw[f"u{unit}c1_b"], flags=EP_BIAS | EP_RELU_OP,
+                        out_op=ws.tmpa[i], ldo_op=ws.tmpa[i].shape[3], map_op=MAP_PAD, map_h=g[0], map_w=g[1])
+            self._conv3(ws.tmpa[i], fw[f"u{unit}c2_w"], rows[i], Fch, g, bias=fw[f"u{unit}c2_b"], res=src_f32, ldr=Fch,
+                        flags=EP_BIAS | EP_RESIDUAL, **out)
+
+        # ---- refinenet4..1 (blocks.py:123-148).  out_conv is applied BEFORE the bilinear resize: both are linear and
+        #      the align_corners weights sum to one, so conv1x1(resize(x)) == resize(conv1x1(x)) at a quarter of the MACs.
+        s_f32, s_pad = ws.rnx[3], ws.rnr[3]
+        for i in (3, 2, 1, 0):
+            fw = w.fuse[i]
+            rcu(i, fw, 2, s_pad, s_f32, out_op=ws.u[i], ldo_op=ws.u[i].shape[1])
+            k_igemm(M=rows[i], N=Fch, K=ws.u[i].shape[1], A=ws.u[i], lda=ws.u[i].shape[1], W=fw["out_w"], bias=fw["out_b"], flags=EP_BIAS,
+                    out_f32=ws.zf[i], ldo_f32=Fch)
+            if i > 0:
+                j = i - 1
+                rcu(j, w.fuse[j], 1, ws.rnr[j], ws.rnx[j], out_f32=ws.r[j], ldo_f32=Fch)
+                k_bilinear(ws.zf[i], Fch, B, grid[i][0], grid[i][1], grid[j][0], grid[j][1], Fch, add=ws.r[j], ld_add=Fch,
+                           out_f32=ws.s[j], ld_f32=Fch, out_op=ws.sr[j], ld_op=ws.sr[j].shape[3], map_op=MAP_PAD, relu=True)
+                s_f32, s_pad = ws.s[j], ws.sr[j]
+        g2 = ws.g296
+        k_bilinear(ws.zf[0], Fch, B, grid[0][0], grid[0][1], g2[0], g2[1], Fch, out_op=ws.p1, ld_op=ws.p1.shape[3], map_op=MAP_PAD)
+
+        # ---- output_conv1 -> resize to (14 ph, 14 pw) -> output_conv2 (3x3, ReLU, 1x1, activation) (dpt.py:193-195) ----
+        self._conv3(ws.p1, w.oc1_w, B * g2[0] * g2[1], ws.half, g2, bias=w.oc1_b, flags=EP_BIAS, out_f32=ws.oc1, ldo_f32=ws.half)
+        k_bilinear(ws.oc1, ws.half, B, g2[0], g2[1], ws.H, ws.W, ws.half, out_op=ws.fin, ld_op=ws.fin.shape[3], map_op=MAP_PAD)
+        out = torch.empty(B, 1, ws.H, ws.W, dtype=torch.float32, device=ws.fin.device)
+        self._conv3(ws.fin, w.oc2_w, B * ws.H * ws.W, w.oc2_w.shape[0], (ws.H, ws.W), bias=w.oc2_b, flags=EP_BIAS | EP_TAIL,
+                    out_f32=out, ldo_f32=1, tail_w=w.tail_w, tail_b=w.tail_b, tail_act=self.final_act)
+        return out

@@ -1,0 +1,157 @@
+"""Guided Depth-Anything-V2: DINOv2 encoder + DPT head with input_projection and Sigmoid tail
+(reference DA2/dpt.py).  ``DepthAnythingV2.forward(x, guidance_mask) -> [B,1,H,W]``.
+
+``forward`` hands the whole pass to ``hip_ext.engine.DepthEngine`` (one fixed launch sequence of HIP
+kernels); the DPTHead / LayerNorm modules below also work standalone through ``hip_ext.functional``.
+"""
+import torch
+import torch.nn as nn
+
+from .dinov2 import DINOv2
+from .util.blocks import FeatureFusionBlock, _make_scratch
+
+INTERMEDIATE_LAYER_IDX = {"vits": [2, 5, 8, 11], "vitb": [2, 5, 8, 11], "vitl": [4, 11, 17, 23], "vitg": [9, 19, 29, 39]}
+
+
+def _make_fusion_block(features, use_bn, size=None):
+    return FeatureFusionBlock(features, nn.ReLU(False), deconv=False, bn=use_bn, expand=False, align_corners=True, size=size)
+
+
+class LayerNorm(nn.Module):
+    """Channels-first / channels-last LayerNorm (reference DA2/dpt.py:37-61); biased variance, eps in the sqrt."""
+
+    def __init__(self, normalized_shape, eps=1e-6, data_format="channels_first"):
+        super().__init__()
+        if data_format not in ("channels_last", "channels_first"):
+            raise NotImplementedError
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.eps, self.data_format, self.normalized_shape = eps, data_format, (normalized_shape,)
+
+    def forward(self, x):
+        from hip_ext import functional as HF
+        if self.data_format == "channels_last":
+            return HF.layer_norm(x, self.weight, self.bias, self.eps)
+        y = HF.layer_norm(x.permute(0, 2, 3, 1).contiguous(), self.weight, self.bias, self.eps)
+        return y.permute(0, 3, 1, 2).contiguous()
+
+
+class DPTHead(nn.Module):
+    """final_act: 'sigmoid' (amodal default), 'none' ('ssi' losses), 'relu' (raw Depth-Anything-V2)."""
+
+    def __init__(self, in_channels, features=256, use_bn=False, out_channels=(256, 512, 1024, 1024), use_clstoken=False,
+                 loss_stategy=None, with_input_projection=True):
+        super().__init__()
+        if use_clstoken or use_bn:
+            raise NotImplementedError("use_clstoken / use_bn are off in every Depth-Anything-V2 configuration")
+        oc = list(out_channels)
+        self.use_clstoken = use_clstoken
+        self.projects = nn.ModuleList([nn.Conv2d(in_channels, c, kernel_size=1) for c in oc])
+        self.resize_layers = nn.ModuleList([
+            nn.ConvTranspose2d(oc[0], oc[0], kernel_size=4, stride=4, padding=0),
+            nn.ConvTranspose2d(oc[1], oc[1], kernel_size=2, stride=2, padding=0),
+            nn.Identity(),
+            nn.Conv2d(oc[3], oc[3], kernel_size=3, stride=2, padding=1)])
+        self.scratch = _make_scratch(oc, features, groups=1, expand=False)
+        self.scratch.stem_transpose = None
+        for k in (1, 2, 3, 4):
+            setattr(self.scratch, f"refinenet{k}", _make_fusion_block(features, use_bn))
+        self.scratch.output_conv1 = nn.Conv2d(features, features // 2, kernel_size=3, stride=1, padding=1)
+        tail = [nn.Conv2d(features // 2, 32, kernel_size=3, stride=1, padding=1), nn.ReLU(True),
+                nn.Conv2d(32, 1, kernel_size=1, stride=1, padding=0)]
+        if not with_input_projection:          # raw model: ReLU, Identity (RAW/dpt.py:109-115)
+            tail += [nn.ReLU(True), nn.Identity()]
+            self.final_act = "relu"
+        elif "ssi" in (loss_stategy or ""):    # DA2/dpt.py:138-144
+            self.final_act = "none"
+        else:                                   # DA2/dpt.py:145-151
+            tail += [nn.Sigmoid()]
+            self.final_act = "sigmoid"
+        self.scratch.output_conv2 = nn.Sequential(*tail)
+        if with_input_projection:               # DA2/dpt.py:153-159
+            self.input_projection = nn.ModuleList(
+                [nn.Sequential(nn.Conv2d(c, c, kernel_size=3, padding=1), LayerNorm([c]), nn.ReLU()) for c in oc])
+
+    def forward(self, out_features, patch_h, patch_w):
+        """Module-level path (reference DA2/dpt.py:161-197) on NCHW fp32 tensors."""
+        from hip_ext import functional as HF
+        layers = []
+        for i, feat in enumerate(out_features):
+            x = feat[0]
+            x = x.permute(0, 2, 1).reshape(x.shape[0], x.shape[-1], patch_h, patch_w)
+            x = HF.conv2d(x, self.projects[i].weight, self.projects[i].bias)
+            r = self.resize_layers[i]
+            if isinstance(r, nn.ConvTranspose2d):
+                x = HF.conv_transpose2d(x, r.weight, r.bias, r.stride[0])
+            elif isinstance(r, nn.Conv2d):
+                x = HF.conv2d(x, r.weight, r.bias, stride=2, padding=1)
+            layers.append(x)
+        if hasattr(self, "input_projection"):
+            for i in range(4):
+                conv, ln, _ = self.input_projection[i]
+                layers[i] = torch.relu(ln(HF.conv2d(layers[i], conv.weight, conv.bias, padding=1)))
+        s = self.scratch
+        rn = [HF.conv2d(layers[i], getattr(s, f"layer{i + 1}_rn").weight, None, padding=1) for i in range(4)]
+        path = s.refinenet4(rn[3], size=rn[2].shape[2:])
+        path = s.refinenet3(path, rn[2], size=rn[1].shape[2:])
+        path = s.refinenet2(path, rn[1], size=rn[0].shape[2:])
+        path = s.refinenet1(path, rn[0])
+        out = HF.conv2d(path, s.output_conv1.weight, s.output_conv1.bias, padding=1)
+        out = HF.interpolate_bilinear_ac(out, (int(patch_h * 14), int(patch_w * 14)))
+        c0, c2 = s.output_conv2[0], s.output_conv2[2]
+        return HF.conv_tail(out, c0.weight, c0.bias, c2.weight, c2.bias, self.final_act)
+
+
+class _EngineMixin:
+    """Lazily builds / refreshes the packed weights + launch plan whenever a parameter changes."""
+
+    def _engine(self):
+        from hip_ext.engine import DepthEngine, PackedWeights
+        params = [(k, v) for k, v in self.state_dict(keep_vars=True).items()]
+        stamp = tuple((v.data_ptr(), v._version) for _, v in params)
+        if getattr(self, "_engine_stamp", None) != stamp:
+            sd = {k: v.detach() for k, v in params}
+            pw = PackedWeights(sd, self.encoder, guided=self.pretrained.has_guidance, amodal_head=hasattr(self.depth_head, "input_projection"))
+            object.__setattr__(self, "_engine_obj", DepthEngine(pw, self.depth_head.final_act, bool(getattr(self, "normalise_input", False))))
+            object.__setattr__(self, "_engine_stamp", stamp)
+        return self._engine_obj
+
+    def _run(self, x, guide):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # inference-only build: autograd through the HIP kernels is not provided (training is out of scope)
+            pass
+        eng = self._engine()
+        B = x.shape[0]
+        step = eng.max_batch(x.shape[-2], x.shape[-1])
+        if B <= step:
+            return eng.forward(x, guide)
+        outs = [eng.forward(x[i:i + step], None if guide is None else guide[i:i + step]).clone() for i in range(0, B, step)]
+        return torch.cat(outs, dim=0)
+
+
+class DepthAnythingV2(nn.Module, _EngineMixin):
+    def __init__(self, encoder="vitl", features=256, out_channels=(256, 512, 1024, 1024), use_bn=False, use_clstoken=False,
+                 guide_type=None, loss_stategy=None):
+        super().__init__()
+        self.intermediate_layer_idx = INTERMEDIATE_LAYER_IDX
+        self.encoder = encoder
+        if guide_type is None:
+            raise NotImplementedError  # reference DA2/dinov2.py:124-125: guided model needs an explicit guide_type
+        self.pretrained = DINOv2(model_name=encoder, guide_type=guide_type)
+        self.depth_head = DPTHead(self.pretrained.embed_dim, features, use_bn, out_channels=out_channels,
+                                  use_clstoken=use_clstoken, loss_stategy=loss_stategy or "")
+        self.normalise_input = False
+
+    def forward(self, x, guidance_mask):
+        return self._run(x, guidance_mask)
+
+    def forward_modular(self, x, guidance_mask):
+        """Module-by-module evaluation (reference DA2/dpt.py:225-231) -- same kernels, unfused; used by tests."""
+        if self.normalise_input:
+            mean = torch.tensor([0.485, 0.456, 0.406], device=x.device).view(-1, 1, 1)
+            std = torch.tensor([0.229, 0.224, 0.225], device=x.device).view(-1, 1, 1)
+            x = (x - mean) / std
+        ph, pw = x.shape[-2] // 14, x.shape[-1] // 14
+        feats = self.pretrained.get_intermediate_layers(x, self.intermediate_layer_idx[self.encoder], return_class_token=True,
+                                                        guidance_mask=guidance_mask)
+        return self.depth_head(feats, ph, pw)

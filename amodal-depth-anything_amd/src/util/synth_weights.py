@@ -1,0 +1,98 @@
+"""Deterministic synthetic weights / inputs for the Amodal-Depth-Anything forward pass.
+
+No checkpoint ships with the reference and there is no network, so parity and
+throughput are measured on weights produced by this generator.  It is bit-reproducible across
+machines running the same torch build: every tensor is drawn from its own CPU ``torch.Generator``
+seeded with crc32(key) ^ seed, so the result does not depend on dict order or on which other
+keys exist.  It works on *any* state_dict with the reference's key schema --
+the reference's, the oracle's or this package's -- which is what lets golden vectors produced
+from the reference in the build container be reproduced on the GPU box.
+
+The fill deliberately (a) overwrites the zero-init of ``patch_embed_guidance`` (reference
+``src/models/amodalsynthdrive/dav2.py:55-61``) so the mask/observation conditioning is live,
+(b) moves LayerNorm / LayerScale gains away from 1, and (c) widens the head's output range so a
+relative-L1 comparison of depth maps is meaningful.
+"""
+import zlib
+from typing import Dict
+
+import torch
+
+
+def _gen(key: str, seed: int) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    return g
+
+
+def _is_norm_key(key: str) -> bool:
+    leaf = key.rsplit(".", 2)
+    if len(leaf) < 2:
+        return False
+    parent = leaf[-2]
+    if parent in ("norm", "norm1", "norm2"):
+        return True
+    # input_projection.{i}.1 is the channels-first LayerNorm (reference DA2/dpt.py:153-159)
+    return "input_projection" in key and parent == "1"
+
+
+@torch.no_grad()
+def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Overwrites every floating tensor of ``sd`` in place; returns ``sd``."""
+    for key, t in sd.items():
+        if not torch.is_floating_point(t):
+            continue
+        g = _gen(key, seed)
+        shape = tuple(t.shape)
+        leaf = key.rsplit(".", 1)[-1]
+
+        def randn(*s):
+            return torch.randn(*s, generator=g, dtype=torch.float32)
+
+        if _is_norm_key(key):
+            v = 1.0 + 0.1 * randn(*shape) if leaf == "weight" else 0.1 * randn(*shape)
+        elif leaf == "gamma":  # LayerScale
+            v = 0.3 + 0.7 * torch.rand(*shape, generator=g, dtype=torch.float32)
+        elif leaf == "cls_token" or leaf == "mask_token":
+            v = 0.5 * randn(*shape)
+        elif leaf == "pos_embed":
+            v = 0.5 * randn(*shape)
+        elif t.ndim >= 2:
+            if "resize_layers.0" in key or "resize_layers.1" in key:
+                fan_in = shape[0]  # ConvTranspose2d [Cin, Cout, k, k], stride == k: Cin terms per output
+            else:
+                fan_in = 1
+                for s in shape[1:]:
+                    fan_in *= s
+            gain = 1.0
+            if "patch_embed_guidance" in key:
+                gain = 2.0
+            v = randn(*shape)
+            if "output_conv2.2" in key:
+                # final 1x1 conv sees post-ReLU (all-positive) features: a zero-mean filter keeps the
+                # logits centred so the sigmoid output spans (0,1) instead of saturating at one end.
+                v = v - v.mean()
+                gain = 3.0
+            v = v * (gain / fan_in ** 0.5)
+        else:  # biases
+            v = 0.1 * randn(*shape)
+        t.copy_(v.to(t.dtype))
+    return sd
+
+
+def make_inputs(batch: int, height: int = 518, width: int = 518, seed: int = 0, device="cpu"):
+    """Synthetic inputs of SURVEY.md §8(d): RGB in [0,1), rectangular amodal mask (+-1),
+    smooth-ish observation in [-1,1].  Returns (x, guide_rgb, guide_mask, observation)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1000003 * seed + 17)
+    x = torch.rand(batch, 3, height, width, generator=g)
+    guide_rgb = torch.rand(batch, 3, height, width, generator=g)
+    obs = torch.rand(batch, 1, height, width, generator=g) * 2 - 1
+    mask = -torch.ones(batch, 1, height, width)
+    for b in range(batch):
+        y0 = int(torch.randint(0, height // 2, (1,), generator=g))
+        x0 = int(torch.randint(0, width // 2, (1,), generator=g))
+        hh = int(torch.randint(height // 8, height // 2, (1,), generator=g))
+        ww = int(torch.randint(width // 8, width // 2, (1,), generator=g))
+        mask[b, :, y0:y0 + hh, x0:x0 + ww] = 1.0
+    return x.to(device), guide_rgb.to(device), mask.to(device), obs.to(device)

@@ -1,0 +1,196 @@
+/*
+ * ada_hip.h -- C ABI of libada_hip.so, the MI355X (gfx950) kernel library behind the
+ * Amodal-Depth-Anything forward pass.
+ *
+ * The reference (zhyever/Amodal-Depth-Anything) has no FFI of its own: its lowest boundary is
+ * the torch.nn / ATen call made by each L1 module.  Every entry point below
+ * therefore names the reference call sites (file:line under /root/reference, DA2 =
+ * src/models/amodalsynthdrive/depth_anything_v2) whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - plain C, raw device pointers, explicit sizes/strides; no torch types.
+ *  - the caller owns every buffer (inputs, outputs, workspaces); the library allocates nothing
+ *    and keeps no global state besides a thread-local last-error string.
+ *  - every launcher is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant,
+ *    and returns 0 on success or a negative ADA_E* code; it never throws or exits.
+ *  - "op" = the contraction-operand type the library was built for: IEEE fp16 by default
+ *    (ada_operand_dtype() == ADA_DT_F16), bf16 with -DADA_OPERAND_BF16.  All accumulation,
+ *    normalisation, softmax, activation and residual arithmetic is fp32.
+ *  - activations of the DPT head are NHWC ("pixel rows"): row = (b*H + y)*W + x, ld = channels
+ *    rounded up to a multiple of 64 (pad columns are zero).  "padded NHWC" additionally has a
+ *    one-pixel zero border: [B, H+2, W+2, ld].
+ */
+#ifndef ADA_HIP_H
+#define ADA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADA_ABI_VERSION 1
+
+/* status codes */
+#define ADA_OK 0
+#define ADA_EINVAL (-1)      /* bad argument (null pointer, negative size, misaligned ld ...) */
+#define ADA_EUNSUPPORTED (-2) /* shape outside what the kernels implement */
+#define ADA_ELAUNCH (-3)     /* HIP reported a launch failure */
+
+/* dtypes */
+#define ADA_DT_F32 0
+#define ADA_DT_F16 1
+#define ADA_DT_BF16 2
+
+int ada_abi_version(void);
+/* ADA_DT_F16 or ADA_DT_BF16: the operand type this build of the library contracts in. */
+int ada_operand_dtype(void);
+/* Text of the last error raised on the calling thread ("" if none). */
+const char* ada_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM contraction with fused epilogue:   C[m, n] = sum_k A(m, k) * W[n, k]
+ *
+ * One MFMA kernel serves every dense contraction of the path:
+ *   nn.Linear            DA2/dinov2_layers/attention.py:51,60 (qkv, proj); mlp.py:36,39 (fc1, fc2);
+ *                        swiglu_ffn.py:30,33 (w12, w3)
+ *   Conv2d 14x14 s14     DA2/dinov2_layers/patch_embed.py:66,76 after ada_patchify (a_mode PLAIN)
+ *   Conv2d 1x1           DA2/dpt.py:172 (projects), DA2/util/blocks.py:146 (out_conv), dpt.py:149
+ *   ConvTranspose2d k=s  DA2/dpt.py:88-100,173 (a_mode PLAIN + o_map SHUFFLE)
+ *   Conv2d 3x3 s1/s2 p1  DA2/dpt.py:101-106,156,135,147; DA2/util/blocks.py:20-24,45-47 (a_mode CONV3)
+ * with epilogues
+ *   + bias                                  (every nn.Linear / Conv2d bias)
+ *   GELU (exact erf)                        DA2/dinov2_layers/mlp.py:37
+ *   * gamma + residual                      layer_scale.py:28 + block.py:105-106
+ *   + residual                              DA2/util/blocks.py:80 (skip_add), dinov2.py:246 (pos_embed)
+ *   ReLU on the operand copy                DA2/util/blocks.py:67,72 (activation before conv1/conv2)
+ *   SiLU(x1)*x2                             swiglu_ffn.py:31-32 (columns interleaved by the packer)
+ *   ReLU -> 1x1 conv (N -> 1) -> Sigmoid/ReLU   DA2/dpt.py:146-151 / RAW dpt.py:109-115 (tail)
+ * ---------------------------------------------------------------------------------------- */
+
+/* a_mode */
+#define ADA_A_PLAIN 0 /* A(m, k) = A[m * lda + k] */
+#define ADA_A_CONV3 1 /* 3x3 window gather from padded NHWC, k = (dy*3+dx)*lda + c */
+
+/* output row maps: GEMM row m -> row of the output buffer */
+#define ADA_MAP_PLAIN 0   /* row = m */
+#define ADA_MAP_PAD 1     /* m=(b,y,x) in [B,Ho,Wo] -> interior of padded NHWC [B,Ho+2,Wo+2] */
+#define ADA_MAP_TOKEN 2   /* m=(b,p) in [B,Np] -> token row b*(Np+1) + 1 + p (skips the cls row) */
+#define ADA_MAP_SHUFFLE 3 /* ConvTranspose k=s: m=(b,y,x) in [B,Ho,Wo], n=(i,j,co) ->
+                             padded NHWC [B, s*Ho+2, s*Wo+2], pixel (s*y+i, s*x+j), column co */
+
+/* epilogue flags */
+#define ADA_EP_BIAS 0x1
+#define ADA_EP_GELU 0x2
+#define ADA_EP_GAMMA 0x4     /* v *= gamma[n] (LayerScale) */
+#define ADA_EP_RESIDUAL 0x8  /* v += res[res_row(m) * ldr + n] (fp32) */
+#define ADA_EP_RELU_OP 0x10  /* ReLU applied to the operand-typed copy only */
+#define ADA_EP_SWIGLU 0x20   /* columns come in (x1, x2) 32-wide groups: out = silu(x1) * x2 */
+#define ADA_EP_TAIL 0x40     /* v = relu(v); d = sum_n v*tail_w[n] + tail_b; out_f32[m] = act(d) */
+#define ADA_EP_RELU_F32 0x80 /* ReLU applied to the fp32 output as well */
+
+/* tail activations */
+#define ADA_ACT_NONE 0
+#define ADA_ACT_SIGMOID 1
+#define ADA_ACT_RELU 2
+
+typedef struct ada_igemm_args {
+    int32_t M, N, K;        /* K = padded contraction length (multiple of 64); for CONV3, K = 9*lda */
+    int32_t a_mode;
+    const void* A;          /* op-typed */
+    int64_t lda;            /* elements; multiple of 64 */
+    /* CONV3 geometry: output grid [B, Ho, Wo]; input padded NHWC [B, Hp, Wp, lda]; stride 1 or 2 */
+    int32_t Ho, Wo, Hp, Wp, stride;
+    const void* W;          /* op-typed [N, K] row-major, K contiguous, zero padded */
+    const float* bias;      /* [N] or NULL */
+    const float* gamma;     /* [N] or NULL */
+    const float* res;       /* fp32 residual or NULL */
+    int64_t ldr;
+    int32_t res_row_mod;    /* >0: res row = (m % res_row_mod) + res_row_off; 0: res row = out_f32 row */
+    int32_t res_row_off;
+    int32_t flags;          /* ADA_EP_* */
+    float* out_f32;         /* fp32 output or NULL (may alias res) */
+    int64_t ldo_f32;
+    int32_t map_f32;        /* ADA_MAP_PLAIN / TOKEN */
+    void* out_op;           /* op-typed output or NULL */
+    int64_t ldo_op;
+    int32_t map_op;         /* ADA_MAP_* */
+    int32_t map_h, map_w;   /* Ho, Wo (PAD / SHUFFLE) or Np in map_h (TOKEN) */
+    int32_t shuffle_s;      /* SHUFFLE: kernel = stride s; N = s*s*shuffle_c */
+    int32_t shuffle_c;
+    const float* tail_w;    /* TAIL: [N] fp32 */
+    float tail_b;
+    int32_t tail_act;
+} ada_igemm_args;
+
+int ada_igemm(const ada_igemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused scaled-dot-product attention, head_dim 64 (all of ViT-S/B/L/G):
+ *   softmax(q k^T) v per (batch, head), q already scaled by head_dim^-0.5 (folded into the qkv
+ *   weights by the packer).  Replaces DA2/dinov2_layers/attention.py:53-59 (and the xformers
+ *   memory_efficient_attention call at :76).  qkv is the packed output of the qkv linear:
+ *   [B*N, 3*heads*64] with column = which*heads*64 + head*64 + d (attention.py:51 reshape).
+ *   out: [B*N, heads*64] op-typed (the "transpose(1,2).reshape(B,N,C)" layout of :59).
+ *   The N x N score matrix is never materialised: K/V tiles of 64 keys are staged through LDS,
+ *   softmax runs online in fp32 registers.
+ * ---------------------------------------------------------------------------------------- */
+int ada_attention_fwd(const void* qkv, void* out, int32_t batch, int32_t n_tokens, int32_t heads,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension, eps inside the sqrt, biased variance, fp32 statistics:
+ *   nn.LayerNorm(D, eps=1e-6)   DA2/dinov2.py:96,185 used at block.py:84,87 and dinov2.py:337-338
+ *   channels-first LayerNorm    DA2/dpt.py:55-61 (on NHWC rows it is the same row-wise op)
+ * in: fp32 [rows, ld_in]; normalises the first `dim` columns of each row.
+ * Row selection: group_in > 0 treats the input as groups of `group_in` rows and skips the first
+ * `skip` rows of each group (drops the cls token: dinov2.py:339-340); output rows are compacted.
+ * Output (either may be NULL): op-typed with row map (PLAIN or PAD) and optional ReLU
+ * (DA2/dpt.py:158), and/or fp32 plain.
+ * ---------------------------------------------------------------------------------------- */
+int ada_layernorm_fwd(const float* in, int64_t ld_in, int32_t rows_out, int32_t dim,
+                      int32_t group_in, int32_t skip,
+                      const float* weight, const float* bias, float eps,
+                      void* out_op, int64_t ld_op, int32_t map_op, int32_t map_h, int32_t map_w,
+                      int32_t relu,
+                      float* out_f32, int64_t ld_f32, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Patchify: the im2col half of the 14x14/stride-14 patch-embed convolutions
+ * (DA2/dinov2_layers/patch_embed.py:76 for RGB, DA2/dinov2.py:239 for the guidance embed) with
+ * the ImageNet normalisation of src/models/amodalsynthdrive/dav2.py:65 fused in.
+ * x: fp32 NCHW [B,3,H,W]; guide: fp32 NCHW [B,Cg,H,W] or NULL (Cg = 0).
+ * out: op-typed [B*(H/14)*(W/14), ld] with column (c*196 + dy*14 + dx), c over RGB then guide
+ * channels; columns >= (3+Cg)*196 are written as zero.  mean/inv_std: [3] fp32 or NULL (raw model,
+ * already normalised by the caller: infer.py:19).
+ * ---------------------------------------------------------------------------------------- */
+int ada_patchify(const float* x, const float* guide, int32_t batch, int32_t cg, int32_t height,
+                 int32_t width, const float* mean, const float* inv_std, void* out, int64_t ld,
+                 void* stream);
+
+/* cls row of the token matrix: tokens[b, 0, :] = cls + pos[0]  (DA2/dinov2.py:245-246). */
+int ada_write_cls(float* tokens, int32_t batch, int32_t n_tokens, int32_t dim, const float* cls,
+                  const float* pos0, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Bilinear resize, align_corners=True, on NHWC fp32 rows, with optional fused skip add:
+ *   out(b,y,x,:) = bilinear(in)(b,y,x,:) [+ add(b,y,x,:)]
+ * Replaces F.interpolate at DA2/util/blocks.py:144 and DA2/dpt.py:194, and the skip_add of
+ * DA2/util/blocks.py:133.  Outputs (either may be NULL): fp32 plain [B*Ho*Wo, ld_f32]; op-typed
+ * with row map PLAIN or PAD and optional ReLU (the activation opening the next ResidualConvUnit,
+ * DA2/util/blocks.py:67).
+ * ---------------------------------------------------------------------------------------- */
+int ada_bilinear_fwd(const float* in, int64_t ld_in, int32_t batch, int32_t hi, int32_t wi,
+                     int32_t ho, int32_t wo, int32_t channels, const float* add, int64_t ld_add,
+                     float* out_f32, int64_t ld_f32, void* out_op, int64_t ld_op, int32_t map_op,
+                     int32_t relu, void* stream);
+
+/* Hardware self-test used by the GPU test-suite: checks the MFMA / LDS-transpose fragment layouts the
+ * kernels assume against a scalar computation on the device.  Returns 0 when they hold,
+ * a positive bit mask of failed probes otherwise.  scratch: >= 1 MiB of device memory. */
+int ada_selftest(void* scratch, int64_t scratch_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADA_HIP_H */

@@ -1,0 +1,59 @@
+"""Shared helpers: rebuild the synthetic weights / inputs of a golden fixture and the product model."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from src.util.synth_weights import fill_state_dict_, make_inputs
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PIXEL_MEAN = (0.485, 0.456, 0.406)
+PIXEL_STD = (0.229, 0.224, 0.225)
+
+
+def golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    return torch.from_numpy(z["out"]), json.loads(str(z["meta"]))
+
+
+def build_product_model(case):
+    """The product nn.Module (parameters on CPU; no compute happens here)."""
+    if case["kind"] == "amodal":
+        from src.models import get_model
+        return get_model("AmodalDAv2", guide_type=case["guide_type"], loss_stategy=case["loss"], encoder=case["encoder"],
+                         pretrained=False).eval()
+    from src.models.amodalsynthdrive.depth_anything_v2_raw.dpt import DepthAnythingV2
+    return DepthAnythingV2(encoder=case["encoder"], features=case["features"], out_channels=case["out_channels"]).eval()
+
+
+def synth_state_dict(model, meta=None, seed=0):
+    """fp32 CPU state_dict with the deterministic synthetic fill (+ the fixture's logit-centring bias)."""
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    fill_state_dict_(sd, seed)
+    if meta is not None:
+        sd[meta["final_bias_key"]] = torch.full_like(sd[meta["final_bias_key"]], meta["final_bias"])
+    return sd
+
+
+def case_inputs(case, seed=0):
+    x, grgb, mask, obs = make_inputs(case["B"], case["H"], case["W"], seed)
+    if case["kind"] == "raw":
+        x = (x - torch.tensor(PIXEL_MEAN).view(-1, 1, 1)) / torch.tensor(PIXEL_STD).view(-1, 1, 1)
+    return x, grgb, mask, obs
+
+
+def oracle_forward(sd, case, x, grgb, mask, obs, **kw):
+    from oracle import dav2_oracle as O
+    if case["kind"] == "raw":
+        return O.raw_forward(sd, case["encoder"], x, **kw)
+    return O.amodal_forward(sd, case["encoder"], case["guide_type"], case["loss"], x, grgb, mask, obs, **kw)
+
+
+def rel_l1(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().mean() / b.abs().mean())

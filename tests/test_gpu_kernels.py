@@ -1,0 +1,301 @@
+"""GPU parity tests of each libada_hip entry point against a plain PyTorch fp32 computation of the same
+op on the same operand-rounded inputs (so the only differences are fp32 summation order)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _op(hip):
+    return hip.operand_dtype()
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _close(got, ref, atol, rtol=2e-3, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs()
+    lim = atol + rtol * ref.abs()
+    bad = err > lim
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.3e} (ref max {float(ref.abs().max()):.3e})"
+
+
+def test_selftest_fragment_layouts(hip):
+    assert hip.selftest() == 0, hip.load().ada_last_error()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (128, 128, 64), (1, 1, 64), (2740, 1152, 384), (257, 48, 192), (515, 32, 128)])
+def test_igemm_plain_bias(hip, M, N, K):
+    op = _op(hip)
+    A = _rand(M, K, seed=1).to(op).to(DEV)
+    W = _rand(N, K, scale=K ** -0.5, seed=2).to(op).to(DEV)
+    b = _rand(N, seed=3).to(DEV)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=W, bias=b, flags=hip.EP_BIAS, out_f32=out, ldo_f32=N)
+    ref = A.float().cpu() @ W.float().cpu().T + b.cpu()
+    _close(out, ref, 2e-4, what="igemm bias")
+
+
+def test_igemm_gelu_operand_out(hip):
+    op = _op(hip)
+    M, N, K = 700, 384, 256
+    A = _rand(M, K, seed=4).to(op).to(DEV)
+    W = _rand(N, K, scale=K ** -0.5, seed=5).to(op).to(DEV)
+    b = _rand(N, seed=6).to(DEV)
+    out = torch.zeros(M, N, dtype=op, device=DEV)
+    hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=W, bias=b, flags=hip.EP_BIAS | hip.EP_GELU, out_op=out, ldo_op=N)
+    ref = F.gelu(A.float().cpu() @ W.float().cpu().T + b.cpu())
+    _close(out, ref, 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="igemm gelu")
+
+
+def test_igemm_layerscale_residual_inplace(hip):
+    op = _op(hip)
+    M, N, K = 1370, 384, 384
+    A = _rand(M, K, seed=7).to(op).to(DEV)
+    W = _rand(N, K, scale=K ** -0.5, seed=8).to(op).to(DEV)
+    b, g = _rand(N, seed=9).to(DEV), _rand(N, seed=10).to(DEV)
+    x = _rand(M, N, seed=11).to(DEV)
+    ref = x.cpu() + (A.float().cpu() @ W.float().cpu().T + b.cpu()) * g.cpu()
+    hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=W, bias=b, gamma=g, res=x, ldr=N,
+              flags=hip.EP_BIAS | hip.EP_GAMMA | hip.EP_RESIDUAL, out_f32=x, ldo_f32=N)
+    _close(x, ref, 3e-4, what="igemm ls+res")
+
+
+def test_igemm_token_map_with_pos(hip):
+    """patch-embed epilogue: rows skip the cls slot, pos_embed added with the row index modulo Np."""
+    op = _op(hip)
+    B, Np, D, K = 3, 50, 128, 192
+    A = _rand(B * Np, K, seed=12).to(op).to(DEV)
+    W = _rand(D, K, scale=K ** -0.5, seed=13).to(op).to(DEV)
+    b = _rand(D, seed=14).to(DEV)
+    pos = _rand(Np + 1, D, seed=15).to(DEV)
+    x = torch.zeros(B * (Np + 1), D, device=DEV)
+    hip.igemm(M=B * Np, N=D, K=K, A=A, lda=K, W=W, bias=b, res=pos, ldr=D, res_row_mod=Np, res_row_off=1,
+              flags=hip.EP_BIAS | hip.EP_RESIDUAL, out_f32=x, ldo_f32=D, map_f32=hip.MAP_TOKEN, map_h=Np)
+    ref = (A.float().cpu() @ W.float().cpu().T + b.cpu()).reshape(B, Np, D) + pos.cpu()[1:]
+    got = x.reshape(B, Np + 1, D).cpu()
+    _close(got[:, 1:], ref, 3e-4, what="token map")
+    assert float(got[:, 0].abs().max()) == 0.0
+
+
+def _pad_nhwc(x_nchw, cp, op):
+    B, C, H, W = x_nchw.shape
+    buf = torch.zeros(B, H + 2, W + 2, cp, dtype=op)
+    buf[:, 1:-1, 1:-1, :C] = x_nchw.permute(0, 2, 3, 1).to(op)
+    return buf
+
+
+def _pack3(w, cp, op):
+    co, ci = w.shape[:2]
+    p = torch.zeros(co, 3, 3, cp)
+    p[..., :ci] = w.permute(0, 2, 3, 1)
+    return p.reshape(co, 9 * cp).to(op)
+
+
+@pytest.mark.parametrize("B,C,H,W,Co,stride", [(2, 64, 19, 19, 64, 1), (1, 48, 37, 37, 96, 1), (2, 128, 37, 37, 128, 2), (1, 64, 30, 23, 200, 1)])
+def test_igemm_conv3x3(hip, B, C, H, W, Co, stride):
+    op = _op(hip)
+    cp = (C + 63) // 64 * 64
+    x = _rand(B, C, H, W, seed=16).to(op).float()
+    w = (_rand(Co, C, 3, 3, seed=17) * (9 * C) ** -0.5).to(op).float()
+    b = _rand(Co, seed=18)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.zeros(B * Ho * Wo, Co, device=DEV)
+    xin = _pad_nhwc(x, cp, op).to(DEV)
+    hip.igemm(M=B * Ho * Wo, N=Co, K=9 * cp, A=xin, lda=cp, W=_pack3(w, cp, op).to(DEV), a_mode=hip.A_CONV3,
+              conv=(Ho, Wo, H + 2, W + 2, stride), bias=b.to(DEV), flags=hip.EP_BIAS, out_f32=out, ldo_f32=Co)
+    ref = F.conv2d(x, w, b, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    _close(out, ref, 3e-4, what="conv3x3")
+
+
+def test_igemm_conv3x3_relu_padded_output_and_residual(hip):
+    op = _op(hip)
+    B, C, H, W = 2, 64, 21, 17
+    x = _rand(B, C, H, W, seed=19).to(op).float()
+    w = (_rand(C, C, 3, 3, seed=20) * (9 * C) ** -0.5).to(op).float()
+    b = _rand(C, seed=21)
+    res = _rand(B * H * W, C, seed=22)
+    out_f = torch.zeros(B * H * W, C, device=DEV)
+    out_p = torch.zeros(B, H + 2, W + 2, C, dtype=op, device=DEV)
+    hip.igemm(M=B * H * W, N=C, K=9 * C, A=_pad_nhwc(x, C, op).to(DEV), lda=C, W=_pack3(w, C, op).to(DEV), a_mode=hip.A_CONV3,
+              conv=(H, W, H + 2, W + 2, 1), bias=b.to(DEV), res=res.to(DEV), ldr=C, flags=hip.EP_BIAS | hip.EP_RESIDUAL | hip.EP_RELU_OP,
+              out_f32=out_f, ldo_f32=C, out_op=out_p, ldo_op=C, map_op=hip.MAP_PAD, map_h=H, map_w=W)
+    ref = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(-1, C) + res
+    _close(out_f, ref, 3e-4, what="conv+res f32")
+    _close(out_p[:, 1:-1, 1:-1].reshape(-1, C), ref.clamp_min(0), 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="conv relu padded")
+    border = out_p.clone()
+    border[:, 1:-1, 1:-1] = 0
+    assert float(border.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("s,C,Ci", [(4, 48, 48), (2, 96, 96), (4, 256, 256)])
+def test_igemm_conv_transpose_shuffle(hip, s, C, Ci):
+    op = _op(hip)
+    B, H, W = 2, 7, 5
+    cp = (Ci + 63) // 64 * 64
+    x = _rand(B, Ci, H, W, seed=23).to(op).float()
+    w = (_rand(Ci, C, s, s, seed=24) * Ci ** -0.5).to(op).float()
+    b = _rand(C, seed=25)
+    A = torch.zeros(B * H * W, cp, dtype=op)
+    A[:, :Ci] = x.permute(0, 2, 3, 1).reshape(-1, Ci).to(op)
+    Wp = torch.zeros(s * s * C, cp)
+    Wp[:, :Ci] = w.permute(2, 3, 1, 0).reshape(s * s * C, Ci)
+    out = torch.zeros(B, s * H + 2, s * W + 2, C, dtype=op, device=DEV)
+    hip.igemm(M=B * H * W, N=s * s * C, K=cp, A=A.to(DEV), lda=cp, W=Wp.to(op).to(DEV), bias=b.repeat(s * s).to(DEV), flags=hip.EP_BIAS,
+              out_op=out, ldo_op=C, map_op=hip.MAP_SHUFFLE, map_h=H, map_w=W, shuffle_s=s, shuffle_c=C)
+    ref = F.conv_transpose2d(x, w, b, stride=s).permute(0, 2, 3, 1)
+    _close(out[:, 1:-1, 1:-1], ref, 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="convT")
+
+
+@pytest.mark.parametrize("act", ["sigmoid", "relu", "none"])
+def test_igemm_tail(hip, act):
+    op = _op(hip)
+    B, C, H, W, Co = 1, 64, 28, 42, 32
+    x = _rand(B, C, H, W, seed=26).to(op).float()
+    w = (_rand(Co, C, 3, 3, seed=27) * (9 * C) ** -0.5).to(op).float()
+    b = _rand(Co, seed=28)
+    tw, tb = _rand(Co, seed=29), 0.25
+    out = torch.zeros(B, 1, H, W, device=DEV)
+    code = {"sigmoid": hip.ACT_SIGMOID, "relu": hip.ACT_RELU, "none": hip.ACT_NONE}[act]
+    hip.igemm(M=B * H * W, N=Co, K=9 * C, A=_pad_nhwc(x, C, op).to(DEV), lda=C, W=_pack3(w, C, op).to(DEV), a_mode=hip.A_CONV3,
+              conv=(H, W, H + 2, W + 2, 1), bias=b.to(DEV), flags=hip.EP_BIAS | hip.EP_TAIL, out_f32=out, ldo_f32=1,
+              tail_w=tw.to(DEV), tail_b=tb, tail_act=code)
+    d = (F.relu(F.conv2d(x, w, b, padding=1)) * tw.view(1, -1, 1, 1)).sum(1, keepdim=True) + tb
+    ref = {"sigmoid": torch.sigmoid, "relu": F.relu, "none": lambda t: t}[act](d)
+    _close(out, ref, 3e-4, what="tail")
+
+
+def test_igemm_swiglu(hip):
+    op = _op(hip)
+    M, K, Hd = 333, 128, 192
+    A = _rand(M, K, seed=30).to(op).to(DEV)
+    w12 = (_rand(2 * Hd, K, seed=31) * K ** -0.5).to(op)
+    b12 = _rand(2 * Hd, seed=32)
+    idx = torch.arange(Hd).reshape(-1, 32)
+    order = torch.stack([idx, idx + Hd], dim=1).reshape(-1)
+    out = torch.zeros(M, Hd, dtype=op, device=DEV)
+    hip.igemm(M=M, N=2 * Hd, K=K, A=A, lda=K, W=w12[order].contiguous().to(DEV), bias=b12[order].contiguous().to(DEV),
+              flags=hip.EP_BIAS | hip.EP_SWIGLU, out_op=out, ldo_op=Hd)
+    x12 = A.float().cpu() @ w12.float().T + b12
+    ref = F.silu(x12[:, :Hd]) * x12[:, Hd:]
+    _close(out, ref, 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="swiglu")
+
+
+@pytest.mark.parametrize("B,N,heads", [(2, 1370, 2), (1, 64, 1), (1, 65, 3), (1, 1, 1), (3, 200, 6)])
+def test_attention(hip, B, N, heads):
+    op = _op(hip)
+    D = heads * 64
+    qkv = _rand(B * N, 3 * D, seed=33).to(op)
+    qkv[:, :D] *= 0.125  # the packer folds head_dim**-0.5 into q
+    qkv = qkv.to(op)
+    out = torch.zeros(B * N, D, dtype=op, device=DEV)
+    hip.attention(qkv.to(DEV), out, B, N, heads)
+    t = qkv.float().reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    p = (t[0] @ t[1].transpose(-2, -1)).softmax(-1)
+    ref = (p @ t[2]).transpose(1, 2).reshape(B * N, D)
+    _close(out, ref, 2e-3, rtol=1e-2 if op == torch.bfloat16 else 3e-3, what="attention")
+
+
+def test_attention_forces_online_rescale(hip):
+    """One key in a late tile dominates: the running max must jump and rescale the accumulated O (T13 hazard)."""
+    op = _op(hip)
+    B, N, heads = 1, 300, 1
+    qkv = _rand(B * N, 192, seed=34) * 0.3
+    qkv[:, 64:128][250] = qkv[:, :64][7] * 40.0   # k_250 aligned with q_7
+    qkv = qkv.to(op)
+    out = torch.zeros(N, 64, dtype=op, device=DEV)
+    hip.attention(qkv.to(DEV), out, B, N, heads)
+    t = qkv.float()
+    p = (t[:, :64] @ t[:, 64:128].T).softmax(-1)
+    _close(out, p @ t[:, 128:], 2e-3, rtol=1e-2 if op == torch.bfloat16 else 3e-3, what="attention rescale")
+
+
+@pytest.mark.parametrize("rows,dim", [(1370, 384), (77, 1024), (5, 1536), (100, 48)])
+def test_layernorm_plain(hip, rows, dim):
+    op = _op(hip)
+    x = _rand(rows, dim, scale=3.0, seed=35) + 0.5
+    w, b = _rand(dim, seed=36), _rand(dim, seed=37)
+    o_op = torch.zeros(rows, dim, dtype=op, device=DEV)
+    o_f = torch.zeros(rows, dim, device=DEV)
+    hip.layernorm(x.to(DEV), dim, rows, dim, w.to(DEV), b.to(DEV), 1e-6, out_op=o_op, ld_op=dim, out_f32=o_f, ld_f32=dim)
+    ref = F.layer_norm(x, (dim,), w, b, 1e-6)
+    _close(o_f, ref, 2e-5, rtol=1e-5, what="ln f32")
+    _close(o_op, ref, 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="ln op")
+
+
+def test_layernorm_drop_cls_and_padded_relu(hip):
+    op = _op(hip)
+    B, N, D = 3, 21, 128   # tokens: 1 cls + 4x5 grid
+    x = _rand(B * N, D, seed=38)
+    w, b = _rand(D, seed=39), _rand(D, seed=40)
+    ref = F.layer_norm(x, (D,), w, b, 1e-6).reshape(B, N, D)[:, 1:]
+    o = torch.zeros(B * (N - 1), D, dtype=op, device=DEV)
+    hip.layernorm(x.to(DEV), D, B * (N - 1), D, w.to(DEV), b.to(DEV), 1e-6, group_in=N, skip=1, out_op=o, ld_op=D)
+    _close(o, ref.reshape(-1, D), 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="ln drop cls")
+    xp = _rand(B * 20, D, seed=41)
+    o2 = torch.zeros(B, 6, 7, D, dtype=op, device=DEV)
+    hip.layernorm(xp.to(DEV), D, B * 20, D, w.to(DEV), b.to(DEV), 1e-6, out_op=o2, ld_op=D, map_op=hip.MAP_PAD, map_h=4, map_w=5, relu=True)
+    ref2 = F.relu(F.layer_norm(xp, (D,), w, b, 1e-6)).reshape(B, 4, 5, D)
+    _close(o2[:, 1:-1, 1:-1], ref2, 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="ln pad relu")
+
+
+@pytest.mark.parametrize("cg", [0, 2, 5])
+def test_patchify(hip, cg):
+    op = _op(hip)
+    B, H, W = 2, 42, 56
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(42))
+    g = torch.rand(B, max(cg, 1), H, W, generator=torch.Generator().manual_seed(43)) * 2 - 1
+    K = (3 + cg) * 196
+    ld = (K + 63) // 64 * 64
+    out = torch.full((B * 12, ld), 7.0, dtype=op, device=DEV)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    hip.patchify(x.to(DEV), g.to(DEV) if cg else None, B, cg, H, W, mean, tuple(1 / s for s in std), out, ld)
+    xn = (x - torch.tensor(mean).view(-1, 1, 1)) / torch.tensor(std).view(-1, 1, 1)
+    full = torch.cat([xn, g], 1) if cg else xn
+    ref = F.unfold(full, 14, stride=14).transpose(1, 2).reshape(B * 12, K)
+    _close(out[:, :K], ref, 1e-3, rtol=1e-2 if op == torch.bfloat16 else 1e-3, what="patchify")
+    assert float(out[:, K:].float().abs().max()) == 0.0 if ld > K else True
+
+
+def test_write_cls(hip):
+    B, N, D = 3, 10, 64
+    t = torch.zeros(B * N, D, device=DEV)
+    cls, pos = _rand(D, seed=44), _rand(N, D, seed=45)
+    hip.write_cls(t, B, N, D, cls.to(DEV), pos.to(DEV))
+    got = t.reshape(B, N, D).cpu()
+    assert torch.equal(got[:, 0], (cls + pos[0]).expand(B, D))
+    assert float(got[:, 1:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("hi,wi,ho,wo", [(19, 19, 37, 37), (37, 37, 74, 74), (8, 5, 16, 10), (20, 30, 35, 49), (3, 3, 1, 1)])
+def test_bilinear_align_corners(hip, hi, wi, ho, wo):
+    op = _op(hip)
+    B, C = 2, 64
+    x = _rand(B, C, hi, wi, seed=46)
+    add = _rand(B * ho * wo, C, seed=47)
+    of = torch.zeros(B * ho * wo, C, device=DEV)
+    oo = torch.zeros(B, ho + 2, wo + 2, C, dtype=op, device=DEV)
+    hip.bilinear(x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV), C, B, hi, wi, ho, wo, C, add=add.to(DEV), ld_add=C,
+                 out_f32=of, ld_f32=C, out_op=oo, ld_op=C, map_op=hip.MAP_PAD, relu=True)
+    ref = F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).reshape(-1, C) + add
+    _close(of, ref, 2e-5, rtol=1e-5, what="bilinear f32")
+    _close(oo[:, 1:-1, 1:-1].reshape(-1, C), ref.clamp_min(0), 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="bilinear op")
+
+
+def test_errors_are_reported_not_thrown(hip):
+    op = _op(hip)
+    A = torch.zeros(64, 64, dtype=op, device=DEV)
+    out = torch.zeros(64, 64, device=DEV)
+    with pytest.raises(hip.HipExtError, match="multiple of 64"):
+        hip.igemm(M=64, N=64, K=48, A=A, lda=64, W=A, out_f32=out, ldo_f32=64)
+    with pytest.raises(hip.HipExtError, match="HIP device"):
+        hip.igemm(M=64, N=64, K=64, A=A.cpu(), lda=64, W=A, out_f32=out, ldo_f32=64)
+    with pytest.raises(hip.HipExtError, match="multiple of the 14-pixel patch"):
+        hip.patchify(torch.zeros(1, 3, 30, 28, device=DEV), None, 1, 0, 30, 28, None, None, torch.zeros(4, 640, dtype=op, device=DEV), 640)

@@ -1,0 +1,78 @@
+"""GPU parity of the whole forward pass: HIP path vs (a) the reference's golden outputs, (b) the fp32 oracle.
+Bar (BASELINE.json north_star): relative L1 of the depth map <= 1e-3, mean|a-b| / mean|b|."""
+import pytest
+import torch
+
+from _cases import build_product_model, case_inputs, golden_names, load_golden, oracle_forward, rel_l1, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _run_product(model, case, x, grgb, mask, obs):
+    model = model.cuda()
+    with torch.no_grad():
+        if case["kind"] == "raw":
+            return model(x.cuda()).cpu()
+        return model(x.cuda(), guide_rgb=grgb.cuda(), guide_mask=mask.cuda(), observation=obs.cuda()).cpu()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_hip_forward_matches_reference_golden(hip, name):
+    gold, meta = load_golden(name)
+    case = meta["case"]
+    model = build_product_model(case)
+    model.load_state_dict(synth_state_dict(model, meta), strict=True)
+    x, grgb, mask, obs = case_inputs(case)
+    out = _run_product(model, case, x, grgb, mask, obs)
+    assert list(out.shape) == meta["out_shape"]
+    assert torch.isfinite(out).all()
+    st = case["stride"]
+    err = rel_l1(out[..., ::st, ::st], gold)
+    print(f"{name}: rel-L1 vs reference golden = {err:.3e}")
+    assert err <= TOL, f"{name}: rel-L1 {err:.3e} > {TOL}"
+
+
+def test_hip_forward_matches_oracle_full_map_and_batch_invariance(hip):
+    """Full-resolution comparison against the oracle run on the box, B=3, plus bs-invariance of the HIP path."""
+    _, meta = load_golden("vits_518")
+    case = dict(meta["case"], B=3)
+    model = build_product_model(case)
+    sd = synth_state_dict(model, meta)
+    model.load_state_dict(sd, strict=True)
+    x, grgb, mask, obs = case_inputs(case)
+    ref = oracle_forward(sd, case, x, grgb, mask, obs)
+    out = _run_product(model, case, x, grgb, mask, obs)
+    err = rel_l1(out, ref)
+    print(f"vits B=3 full map: rel-L1 vs oracle = {err:.3e}")
+    assert err <= TOL
+    with torch.no_grad():
+        one = model(x[1:2].cuda(), guide_rgb=None, guide_mask=mask[1:2].cuda(), observation=obs[1:2].cuda()).cpu()
+    assert torch.equal(one[0], out[1]), "HIP path is not batch invariant"
+
+
+def test_state_dict_reload_repacks(hip):
+    """load_state_dict after a forward must invalidate the packed operand copies."""
+    _, meta = load_golden("vits_g_mask")
+    case = meta["case"]
+    model = build_product_model(case)
+    model.load_state_dict(synth_state_dict(model, meta), strict=True)
+    x, grgb, mask, obs = case_inputs(case)
+    a = _run_product(model, case, x, grgb, mask, obs)
+    model.load_state_dict({k: v.cuda() for k, v in synth_state_dict(model, meta, seed=5).items()}, strict=True)
+    b = _run_product(model, case, x, grgb, mask, obs)
+    assert rel_l1(a, b) > 1e-2
+    model.load_state_dict(synth_state_dict(model, meta), strict=True)
+    c = _run_product(model, case, x, grgb, mask, obs)
+    assert torch.equal(a, c)
+
+
+def test_cpu_tensors_are_rejected(hip):
+    _, meta = load_golden("vits_g_mask")
+    case = meta["case"]
+    model = build_product_model(case).cuda()
+    x, grgb, mask, obs = case_inputs(case)
+    with pytest.raises(hip.HipExtError):
+        model(x, guide_rgb=None, guide_mask=mask, observation=obs)
+    with pytest.raises(AssertionError, match="not a multiple of patch"):
+        model(torch.zeros(1, 3, 100, 98).cuda(), guide_rgb=None, guide_mask=torch.zeros(1, 1, 100, 98).cuda(), observation=None)

@@ -1,21 +1,30 @@
 // Implicit-GEMM contraction with fused epilogues (see include/ada_hip.h: ada_igemm).
 //
-// Tiling (gfx950): a workgroup of 4 waves computes a BM x BN output tile with BK = 64; each wave owns
-// TI x TJ MFMA tiles of 32x32 (v_mfma_f32_32x32x16, fp32 accumulate).  A and W k-slabs (rows of 64
-// operands = 128 B) are copied HBM -> LDS with 16-byte global_load_lds (no VGPR round trip), two LDS
-// stages, one barrier per k-step.  LDS rows are stored linearly (a global_load_lds constraint: the
-// destination is wave base + lane*16) but each lane *fetches* the 16-byte chunk
-// c ^ ((row>>1)&7) of its row, and the MFMA fragment reads apply the same XOR, which makes every
-// ds_read_b128 lane group hit 16 distinct 16-byte bank slots (cdna_hip_programming.md T2 / rule 21).
-//
+// Tiling (gfx950).  A workgroup computes a BM x BN output tile with BK = 64; each wave owns TI x TJ MFMA
+// tiles of 32x32 (v_mfma_f32_32x32x16, fp32 accumulate).  Tile shapes:
+//     256 x 256, 8 waves (2 x 4), wave tile 128 x 64   -- the workhorse: 128 FLOP per LDS byte staged, so the
+//                                                        L2 -> LDS stream stays well under the L2 roofline
+//     256 x 128, 8 waves (4 x 2), wave tile  64 x 64   -- N = 128 (output_conv1)
+//     128 x  64 / 256 x 32, 4 waves                    -- narrow outputs (ViT-S projections, the 32-channel tail conv)
+// A and W k-slabs (rows of 64 operands = 128 B) go HBM/L2 -> LDS with 16-byte global_load_lds (no VGPR round
+// trip), two LDS stages, one barrier per k-step; the loads of slab t+1 are in flight during the MFMAs of slab t.
+// LDS rows are stored linearly (global_load_lds writes wave base + lane*16) but each lane *fetches* chunk
+// c ^ ((row>>1)&7) of its row and the fragment reads apply the same XOR, so every ds_read_b128 lane group
+// hits 16 distinct 16-byte bank slots (cdna_hip_programming.md T2 / rule 21).
 // For a 3x3 convolution the A slab of k-step (tap, kc) is the same 128-byte row segment shifted by
-// (dy*Wp + dx) pixels in the zero-bordered NHWC input, so the gather costs one scalar add per k-step.
+// (dy*Wp + dx) pixels in the zero-bordered NHWC input: the im2col gather costs one scalar add per k-step.
+//
+// Epilogue.  Accumulators are transposed through LDS (wave-private 32-row slabs, fp32) so that every lane then
+// owns 4 consecutive columns of a row: bias / LayerScale / residual / activation run on float4, and the
+// fp32 (16 B) and operand-typed (8 B) stores are contiguous 128-256 B row segments.
 #include <stdarg.h>
 #include "ada_common.h"
 
 namespace {
 
 constexpr int BK = 64;
+
+enum { EPI_STD = 0, EPI_GELU = 1, EPI_SHUFFLE = 2, EPI_SWIGLU = 3, EPI_TAIL = 4 };
 
 struct IgemmDev {
     int M, N, K, a_mode;
@@ -65,16 +74,26 @@ ADA_DEV long map_row(const IgemmDev& p, int map, uint32_t m) {
     return ((long)b * (p.map_h + 2) + (y + 1)) * (p.map_w + 2) + (x + 1);
 }
 
-template <int WAVES_M, int WAVES_N, int TI, int TJ>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmDev p) {
-    constexpr int BM = WAVES_M * TI * 32;
-    constexpr int BN = WAVES_N * TJ * 32;
+ADA_DEV opx4 pack4(float4 v) {
+    opx4 o;
+    o[0] = to_op(v.x); o[1] = to_op(v.y); o[2] = to_op(v.z); o[3] = to_op(v.w);
+    return o;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmDev p) {
+    constexpr int NWAVES = WAVES_M * WAVES_N;
+    constexpr int NT = NWAVES * 64;
+    constexpr int TI = BM / (WAVES_M * 32);
+    constexpr int TJ = BN / (WAVES_N * 32);
     constexpr int A_BYTES = BM * BK * 2;
     constexpr int B_BYTES = BN * BK * 2;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int A_IT = BM / 32;  // 32 rows (x 8 chunks) per 256-thread pass
-    constexpr int B_IT = BN / 32;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int ROWS_PER_PASS = NT / 8;  // 8 lanes (16-byte chunks) per 128-byte row
+    constexpr int A_IT = BM / ROWS_PER_PASS;
+    constexpr int B_IT = BN / ROWS_PER_PASS;
+    static_assert(A_IT >= 1 && B_IT >= 1, "tile smaller than one staging pass");
+    static_assert(TJ == 1 || TJ == 2, "wave tile is 32 or 64 columns wide");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -97,13 +116,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmDev p) {
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- per-thread staging addresses --------------------------------------------------
-    const int srow = tid >> 3;                         // row inside a 32-row pass
-    const int gchunk = (tid & 7) ^ ((tid >> 4) & 7);   // swizzled source chunk of that row
+    const int srow = tid >> 3;                        // row inside a staging pass
+    const int gchunk = (tid & 7) ^ ((tid >> 4) & 7);  // swizzled source chunk: key (row>>1)&7 == (tid>>4)&7
     const op_t* a_ptr[A_IT];
     const op_t* b_ptr[B_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        uint32_t m = (uint32_t)(m0 + it * 32 + srow);
+        uint32_t m = (uint32_t)(m0 + it * ROWS_PER_PASS + srow);
         if (m >= (uint32_t)p.M) m = (uint32_t)p.M - 1;
         long base;
         if (p.a_mode == ADA_A_PLAIN) {
@@ -118,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmDev p) {
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        int n = n0 + it * 32 + srow;
+        int n = n0 + it * ROWS_PER_PASS + srow;
         if (n >= p.N) n = p.N - 1;
         b_ptr[it] = p.W + (long)n * p.K + gchunk * 8;
     }
@@ -139,12 +158,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmDev p) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[it] + aoff),
-                                             (__attribute__((address_space(3))) void*)(sa + it * 4096), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[it] + boff),
-                                             (__attribute__((address_space(3))) void*)(sb + it * 4096), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sb + it * (NT * 16)), 16, 0, 0);
         }
     };
 
@@ -159,7 +178,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmDev p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int swz = (l31 >> 1) & 7;
-    // fragment row byte offsets inside a stage (row * 128 B)
     const int a_row_off = (wm * TI * 32 + l31) * 128;
     const int b_row_off = A_BYTES + (wn * TJ * 32 + l31) * 128;
 
@@ -186,126 +204,135 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmDev p) {
         }
     }
 
-    // ---- epilogue ------------------------------------------------------------------------
+    // ---- epilogue: transpose through a wave-private LDS slab, then float4 per lane ----------------
+    __syncthreads();  // every wave is done reading the last stage before the slabs overwrite it
+    constexpr int WCOLS = TJ * 32;                    // columns of this wave's tile
+    float* slab = (float*)(smem + wave * (32 * WCOLS * 4));
     const int flags = p.flags;
-    int ncol[TJ];
-    float biasv[TJ], gammav[TJ], tailw[TJ];
-    bool nvalid[TJ];
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-        ncol[j] = n0 + (wn * TJ + j) * 32 + l31;
-        nvalid[j] = ncol[j] < p.N;
-        const int nc = nvalid[j] ? ncol[j] : 0;
-        biasv[j] = (flags & ADA_EP_BIAS) ? p.bias[nc] : 0.0f;
-        gammav[j] = (flags & ADA_EP_GAMMA) ? p.gamma[nc] : 1.0f;
-        tailw[j] = ((flags & ADA_EP_TAIL) && nvalid[j]) ? p.tail_w[nc] : 0.0f;
-    }
+    const int nbase = n0 + wn * WCOLS;
+    const int mbase = m0 + wm * TI * 32;
 
-    if (flags & ADA_EP_TAIL) {
-        // relu(conv + bias) . tail_w + tail_b -> activation; one output per GEMM row.  N <= BN, WAVES_N == 1.
+    if constexpr (EPI == EPI_SWIGLU) {
+        // packer interleaved the w12 rows in 32-wide groups: columns [0,32) of the wave tile = x1, [32,64) = x2
+        static_assert(TJ == 2 || EPI != EPI_SWIGLU, "SwiGLU needs a 64-column wave tile");
+        const int c8 = lane & 7, rsub = lane >> 3;
+        const int n1 = nbase + 4 * c8;
+        const bool nval = n1 + 32 < p.N;
+        float4 b1 = make_float4(0, 0, 0, 0), b2 = b1;
+        if (nval && (flags & ADA_EP_BIAS)) {
+            b1 = *(const float4*)(p.bias + n1);
+            b2 = *(const float4*)(p.bias + n1 + 32);
+        }
+        const int nh = (nbase >> 1) + 4 * c8;  // hidden column
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TI + i) * 32 + crow32(r, hi);
-                float part = 0.0f;
+            for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    float v = acc[i][j][r] + biasv[j];
-                    part += __builtin_fmaxf(v, 0.0f) * tailw[j];
-                }
-                // sum over the 32 lanes that share this row (xor shuffles stay inside a 32-lane half)
-                part += __shfl_xor(part, 1);
-                part += __shfl_xor(part, 2);
-                part += __shfl_xor(part, 4);
-                part += __shfl_xor(part, 8);
-                part += __shfl_xor(part, 16);
-                if (l31 == 0 && m < p.M) {
-                    float d = part + p.tail_b;
-                    if (p.tail_act == ADA_ACT_SIGMOID) d = 1.0f / (1.0f + __expf(-d));
-                    else if (p.tail_act == ADA_ACT_RELU) d = __builtin_fmaxf(d, 0.0f);
-                    p.out_f32[m] = d;
+                for (int r = 0; r < 16; ++r) slab[crow32(r, hi) * WCOLS + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = k * 8 + rsub;
+                const int m = mbase + i * 32 + row;
+                const float4 x1 = *(const float4*)(slab + row * WCOLS + 4 * c8);
+                const float4 x2 = *(const float4*)(slab + row * WCOLS + 32 + 4 * c8);
+                if (m < p.M && nval) {
+                    float4 g;
+                    float t;
+                    t = x1.x + b1.x; g.x = t / (1.0f + __expf(-t)) * (x2.x + b2.x);
+                    t = x1.y + b1.y; g.y = t / (1.0f + __expf(-t)) * (x2.y + b2.y);
+                    t = x1.z + b1.z; g.z = t / (1.0f + __expf(-t)) * (x2.z + b2.z);
+                    t = x1.w + b1.w; g.w = t / (1.0f + __expf(-t)) * (x2.w + b2.w);
+                    *(opx4*)(p.out_op + (long)m * p.ldo_op + nh) = pack4(g);
                 }
             }
         }
         return;
-    }
-
-    if (flags & ADA_EP_SWIGLU) {
-        // packer interleaves the w12 rows in 32-wide groups: MFMA tile j = x1 group, tile j+1 = its x2 group
-        if constexpr (TJ % 2 == 0) {
+    } else {
+        constexpr int CG = WCOLS / 4;    // float4 column groups per row (8 or 16)
+        constexpr int RPI = 64 / CG;     // rows covered by one wave-wide float4 read (8 or 4)
+        const int cg = lane % CG, rsub = lane / CG;
+        const int n = nbase + 4 * cg;
+        const bool nval = n < p.N;       // N % 4 == 0 is checked on the host
+        float4 bias4 = make_float4(0, 0, 0, 0), gamma4 = make_float4(1, 1, 1, 1), tail4 = make_float4(0, 0, 0, 0);
+        if (nval) {
+            if (flags & ADA_EP_BIAS) bias4 = *(const float4*)(p.bias + n);
+            if (flags & ADA_EP_GAMMA) gamma4 = *(const float4*)(p.gamma + n);
+            if constexpr (EPI == EPI_TAIL) tail4 = *(const float4*)(p.tail_w + n);
+        }
+        uint32_t sh_i = 0, sh_j = 0, sh_co = 0;
+        if constexpr (EPI == EPI_SHUFFLE) {
+            uint32_t ij;
+            fast_divmod((uint32_t)(nval ? n : 0), p.dShC, ij, sh_co);
+            fast_divmod(ij, p.dShS, sh_i, sh_j);
+        }
 #pragma unroll
-            for (int i = 0; i < TI; ++i) {
+        for (int i = 0; i < TI; ++i) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + (wm * TI + i) * 32 + crow32(r, hi);
-                    if (m < p.M) {
+            for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                        for (int j = 0; j < TJ; j += 2) {
-                            if (nvalid[j]) {
-                                const float x1 = acc[i][j][r] + biasv[j];
-                                const float x2 = acc[i][j + 1][r] + biasv[j + 1];
-                                const float g = x1 / (1.0f + __expf(-x1)) * x2;
-                                const int nh = (ncol[j] >> 6) * 32 + l31;  // hidden column
-                                p.out_op[(long)m * p.ldo_op + nh] = to_op(g);
-                            }
+                for (int r = 0; r < 16; ++r) slab[crow32(r, hi) * WCOLS + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+            for (int k = 0; k < 32 / RPI; ++k) {
+                const int row = k * RPI + rsub;
+                const int m = mbase + i * 32 + row;
+                float4 v = *(const float4*)(slab + row * WCOLS + 4 * cg);
+                v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                if constexpr (EPI == EPI_TAIL) {
+                    float part = __builtin_fmaxf(v.x, 0.f) * tail4.x + __builtin_fmaxf(v.y, 0.f) * tail4.y +
+                                 __builtin_fmaxf(v.z, 0.f) * tail4.z + __builtin_fmaxf(v.w, 0.f) * tail4.w;
+#pragma unroll
+                    for (int o = 1; o < CG; o <<= 1) part += __shfl_xor(part, o);
+                    if (cg == 0 && m < p.M) {
+                        float d = part + p.tail_b;
+                        if (p.tail_act == ADA_ACT_SIGMOID) d = 1.0f / (1.0f + __expf(-d));
+                        else if (p.tail_act == ADA_ACT_RELU) d = __builtin_fmaxf(d, 0.0f);
+                        p.out_f32[m] = d;
+                    }
+                } else {
+                    if (m < p.M && nval) {
+                        if constexpr (EPI == EPI_GELU) {
+                            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
                         }
-                    }
-                }
-            }
-        }
-        return;
-    }
-
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + (wm * TI + i) * 32 + crow32(r, hi);
-            if (m < p.M) {
-                long frow = 0, orow = 0, rrow = 0;
-                uint32_t sb = 0, sy = 0, sx = 0;
-                if (p.out_f32 || (flags & ADA_EP_RESIDUAL)) frow = map_row(p, p.map_f32, (uint32_t)m);
-                if (flags & ADA_EP_RESIDUAL) {
-                    if (p.res_row_mod > 0) {
-                        uint32_t qq, rr;
-                        fast_divmod((uint32_t)m, p.dResMod, qq, rr);
-                        rrow = (long)rr + p.res_row_off;
-                    } else {
-                        rrow = frow;
-                    }
-                }
-                if (p.out_op) {
-                    if (p.map_op == ADA_MAP_SHUFFLE) {
-                        uint32_t rem;
-                        fast_divmod((uint32_t)m, p.dMapHW, sb, rem);
-                        fast_divmod(rem, p.dMapW, sy, sx);
-                    } else {
-                        orow = map_row(p, p.map_op, (uint32_t)m);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    if (nvalid[j]) {
-                        const int n = ncol[j];
-                        float v = acc[i][j][r] + biasv[j];
-                        if (flags & ADA_EP_GELU) v = gelu_erf(v);
-                        v *= gammav[j];
-                        if (flags & ADA_EP_RESIDUAL) v += p.res[rrow * p.ldr + n];
-                        if (p.out_f32) p.out_f32[frow * p.ldo_f32 + n] = (flags & ADA_EP_RELU_F32) ? __builtin_fmaxf(v, 0.0f) : v;
-                        if (p.out_op) {
-                            const float vo = (flags & ADA_EP_RELU_OP) ? __builtin_fmaxf(v, 0.0f) : v;
-                            if (p.map_op == ADA_MAP_SHUFFLE) {
-                                uint32_t ij, co, ii, jj;
-                                fast_divmod((uint32_t)n, p.dShC, ij, co);
-                                fast_divmod(ij, p.dShS, ii, jj);
-                                const long prow = ((long)sb * (p.shuffle_s * p.map_h + 2) + (p.shuffle_s * sy + ii + 1)) *
-                                                      (p.shuffle_s * p.map_w + 2) +
-                                                  (p.shuffle_s * sx + jj + 1);
-                                p.out_op[prow * p.ldo_op + co] = to_op(vo);
-                            } else {
-                                p.out_op[orow * p.ldo_op + n] = to_op(vo);
+                        v.x *= gamma4.x; v.y *= gamma4.y; v.z *= gamma4.z; v.w *= gamma4.w;
+                        long frow = 0;
+                        if (p.out_f32 || (flags & ADA_EP_RESIDUAL)) frow = map_row(p, p.map_f32, (uint32_t)m);
+                        if (flags & ADA_EP_RESIDUAL) {
+                            long rrow = frow;
+                            if (p.res_row_mod > 0) {
+                                uint32_t qq, rr;
+                                fast_divmod((uint32_t)m, p.dResMod, qq, rr);
+                                rrow = (long)rr + p.res_row_off;
                             }
+                            const float4 rv = *(const float4*)(p.res + rrow * p.ldr + n);
+                            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                        }
+                        if (p.out_f32) {
+                            float4 w = v;
+                            if (flags & ADA_EP_RELU_F32) {
+                                w.x = __builtin_fmaxf(w.x, 0.f); w.y = __builtin_fmaxf(w.y, 0.f);
+                                w.z = __builtin_fmaxf(w.z, 0.f); w.w = __builtin_fmaxf(w.w, 0.f);
+                            }
+                            *(float4*)(p.out_f32 + frow * p.ldo_f32 + n) = w;
+                        }
+                        if (p.out_op) {
+                            if (flags & ADA_EP_RELU_OP) {
+                                v.x = __builtin_fmaxf(v.x, 0.f); v.y = __builtin_fmaxf(v.y, 0.f);
+                                v.z = __builtin_fmaxf(v.z, 0.f); v.w = __builtin_fmaxf(v.w, 0.f);
+                            }
+                            long orow;
+                            int ocol = n;
+                            if constexpr (EPI == EPI_SHUFFLE) {
+                                uint32_t sb, rem, sy, sx;
+                                fast_divmod((uint32_t)m, p.dMapHW, sb, rem);
+                                fast_divmod(rem, p.dMapW, sy, sx);
+                                orow = ((long)sb * (p.shuffle_s * p.map_h + 2) + (p.shuffle_s * sy + sh_i + 1)) *
+                                           (p.shuffle_s * p.map_w + 2) + (p.shuffle_s * sx + sh_j + 1);
+                                ocol = (int)sh_co;
+                            } else {
+                                orow = map_row(p, p.map_op, (uint32_t)m);
+                            }
+                            *(opx4*)(p.out_op + orow * p.ldo_op + ocol) = pack4(v);
                         }
                     }
                 }
@@ -314,14 +341,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmDev p) {
     }
 }
 
-template <int WAVES_M, int WAVES_N, int TI, int TJ>
-int launch_igemm(IgemmDev& d, hipStream_t stream) {
-    constexpr int BM = WAVES_M * TI * 32;
-    constexpr int BN = WAVES_N * TJ * 32;
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+int launch_cfg(IgemmDev& d, hipStream_t stream) {
+    constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int SMEM = 2 * (BM + BN) * BK * 2;
     d.tiles_m = (d.M + BM - 1) / BM;
     d.tiles_n = (d.N + BN - 1) / BN;
-    auto kern = igemm_kernel<WAVES_M, WAVES_N, TI, TJ>;
+    auto kern = igemm_kernel<BM, BN, WAVES_M, WAVES_N, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
@@ -330,8 +356,31 @@ int launch_igemm(IgemmDev& d, hipStream_t stream) {
         attr_done = true;
     }
     const long nblk = (long)d.tiles_m * d.tiles_n;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), SMEM, stream, d);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), SMEM, stream, d);
     return ada_check_launch("ada_igemm");
+}
+
+template <int EPI>
+int launch_epi(IgemmDev& d, hipStream_t s, int force) {
+    // tile choice: widest tile whose column count the problem fills; `force` (ADA_IGEMM_TILE env) is for A/B tests
+    int cfg;
+    if (d.N <= 32) cfg = 0;
+    else if (d.N <= 64) cfg = 1;
+    else if (d.N <= 128) cfg = 2;
+    else cfg = 3;
+    if (d.M < 256 && cfg >= 2) cfg = 4;
+    if (force >= 0) cfg = force;
+    if constexpr (EPI == EPI_SWIGLU) {
+        return cfg == 4 ? launch_cfg<128, 128, 2, 2, EPI>(d, s) : launch_cfg<256, 256, 2, 4, EPI>(d, s);
+    } else {
+        switch (cfg) {
+            case 0: return launch_cfg<256, 32, 4, 1, EPI>(d, s);
+            case 1: return launch_cfg<128, 64, 4, 1, EPI>(d, s);
+            case 2: return launch_cfg<256, 128, 4, 2, EPI>(d, s);
+            case 4: return launch_cfg<128, 128, 2, 2, EPI>(d, s);
+            default: return launch_cfg<256, 256, 2, 4, EPI>(d, s);
+        }
+    }
 }
 
 }  // namespace
@@ -360,21 +409,33 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     ADA_REQUIRE(!(f & ADA_EP_BIAS) || a->bias, ADA_EINVAL, "ada_igemm: EP_BIAS without bias");
     ADA_REQUIRE(!(f & ADA_EP_GAMMA) || a->gamma, ADA_EINVAL, "ada_igemm: EP_GAMMA without gamma");
     ADA_REQUIRE(!(f & ADA_EP_RESIDUAL) || a->res, ADA_EINVAL, "ada_igemm: EP_RESIDUAL without res");
-    if (f & ADA_EP_TAIL) {
+    const bool tail = (f & ADA_EP_TAIL) != 0, swiglu = (f & ADA_EP_SWIGLU) != 0;
+    const bool shuffle = a->out_op && a->map_op == ADA_MAP_SHUFFLE;
+    ADA_REQUIRE(a->N % 4 == 0, ADA_EUNSUPPORTED, "ada_igemm: N=%d must be a multiple of 4", a->N);
+    ADA_REQUIRE(!a->out_f32 || tail || (a->ldo_f32 % 4 == 0 && ((uintptr_t)a->out_f32 % 16) == 0), ADA_EINVAL, "ada_igemm: out_f32 must be 16-byte aligned with ldo %% 4 == 0");
+    ADA_REQUIRE(!a->out_op || (a->ldo_op % 4 == 0 && ((uintptr_t)a->out_op % 8) == 0), ADA_EINVAL, "ada_igemm: out_op must be 8-byte aligned with ldo %% 4 == 0");
+    ADA_REQUIRE(!(f & ADA_EP_RESIDUAL) || (a->ldr % 4 == 0 && ((uintptr_t)a->res % 16) == 0), ADA_EINVAL, "ada_igemm: res must be 16-byte aligned with ldr %% 4 == 0");
+    ADA_REQUIRE(!(f & ADA_EP_BIAS) || ((uintptr_t)a->bias % 16) == 0, ADA_EINVAL, "ada_igemm: bias must be 16-byte aligned");
+    ADA_REQUIRE(!(f & ADA_EP_GAMMA) || ((uintptr_t)a->gamma % 16) == 0, ADA_EINVAL, "ada_igemm: gamma must be 16-byte aligned");
+    if (tail) {
         ADA_REQUIRE(a->tail_w && a->out_f32, ADA_EINVAL, "ada_igemm: EP_TAIL needs tail_w and out_f32");
+        ADA_REQUIRE(((uintptr_t)a->tail_w % 16) == 0, ADA_EINVAL, "ada_igemm: tail_w must be 16-byte aligned");
         ADA_REQUIRE(a->N <= 64, ADA_EUNSUPPORTED, "ada_igemm: EP_TAIL supports N <= 64 (got %d)", a->N);
+        ADA_REQUIRE(!swiglu && !shuffle && !(f & ADA_EP_GELU), ADA_EUNSUPPORTED, "ada_igemm: EP_TAIL cannot be combined with other epilogues");
     }
-    if (f & ADA_EP_SWIGLU) {
+    if (swiglu) {
         ADA_REQUIRE(a->N % 64 == 0 && a->out_op && !a->out_f32, ADA_EINVAL, "ada_igemm: EP_SWIGLU needs N %% 64 == 0 and only out_op");
-        ADA_REQUIRE(a->map_op == ADA_MAP_PLAIN, ADA_EUNSUPPORTED, "ada_igemm: EP_SWIGLU supports MAP_PLAIN only");
+        ADA_REQUIRE(a->map_op == ADA_MAP_PLAIN && !(f & (ADA_EP_GELU | ADA_EP_GAMMA | ADA_EP_RESIDUAL)), ADA_EUNSUPPORTED,
+                    "ada_igemm: EP_SWIGLU supports bias + MAP_PLAIN only");
     }
     const int maps_needing_grid = (a->out_op && (a->map_op == ADA_MAP_PAD || a->map_op == ADA_MAP_SHUFFLE));
     if (maps_needing_grid) {
         ADA_REQUIRE(a->map_h > 0 && a->map_w > 0 && a->M % (a->map_h * a->map_w) == 0, ADA_EINVAL, "ada_igemm: bad output grid %dx%d for M=%d", a->map_h, a->map_w, a->M);
     }
-    if (a->out_op && a->map_op == ADA_MAP_SHUFFLE) {
+    if (shuffle) {
         ADA_REQUIRE(a->shuffle_s > 0 && a->shuffle_c > 0 && a->N == a->shuffle_s * a->shuffle_s * a->shuffle_c, ADA_EINVAL,
                     "ada_igemm: SHUFFLE needs N == s*s*c");
+        ADA_REQUIRE(a->shuffle_c % 4 == 0 && !a->out_f32 && !(f & ADA_EP_GELU), ADA_EUNSUPPORTED, "ada_igemm: SHUFFLE needs c %% 4 == 0, operand output only");
     }
     if ((a->out_f32 && a->map_f32 == ADA_MAP_TOKEN) || (a->out_op && a->map_op == ADA_MAP_TOKEN)) {
         ADA_REQUIRE(a->map_h > 0 && a->M % a->map_h == 0, ADA_EINVAL, "ada_igemm: TOKEN map needs map_h = patches per image");
@@ -403,9 +464,17 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.dShS = make_fastdiv(a->shuffle_s > 0 ? a->shuffle_s : 1);
     d.tail_w = a->tail_w; d.tail_b = a->tail_b; d.tail_act = a->tail_act;
     d.cps = (int)(a->lda / BK);
+    d.tiles_m = d.tiles_n = 0;
 
+    static int force = -2;
+    if (force == -2) {
+        const char* e = getenv("ADA_IGEMM_TILE");
+        force = e ? atoi(e) : -1;
+    }
     hipStream_t s = (hipStream_t)stream;
-    if (a->N <= 32) return launch_igemm<4, 1, 2, 1>(d, s);   // 256 x 32 tile
-    if (a->N <= 64) return launch_igemm<4, 1, 1, 2>(d, s);   // 128 x 64 tile
-    return launch_igemm<2, 2, 2, 2>(d, s);                                        // 128 x 128 tile
+    if (tail) return launch_epi<EPI_TAIL>(d, s, a->N <= 32 ? 0 : 1);
+    if (swiglu) return launch_epi<EPI_SWIGLU>(d, s, force);
+    if (shuffle) return launch_epi<EPI_SHUFFLE>(d, s, force);
+    if (f & ADA_EP_GELU) return launch_epi<EPI_GELU>(d, s, force);
+    return launch_epi<EPI_STD>(d, s, force);
 }

@@ -18,6 +18,7 @@
 // owns 4 consecutive columns of a row: bias / LayerScale / residual / activation run on float4, and the
 // fp32 (16 B) and operand-typed (8 B) stores are contiguous 128-256 B row segments.
 #include <stdarg.h>
+#include <stdlib.h>
 #include "ada_common.h"
 
 namespace {
@@ -55,9 +56,20 @@ struct IgemmDev {
     int tail_act;
     int tiles_m, tiles_n;
     int cps;  // k-steps per conv tap = lda / 64
+    int sched;  // main-loop schedule (ADA_IGEMM_SCHED, see the kernel)
+    unsigned long long* dbg;  // optional per-block timestamps (ada_debug_set_timestamps)
+    int skew;   // first-round blocks on odd CUs sleep skew*8k cycles so CUs run out of phase (epilogue bursts overlap MFMA)
 };
 
-ADA_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (nn.GELU default, reference mlp.py:23).  erf through the Abramowitz-Stegun 7.1.26 rational form
+// (|abs err| <= 1.5e-7, i.e. fp32-roundoff class) -- a third of the instructions of the libm erff in the hot epilogue.
+ADA_DEV float gelu_erf(float x) {
+    const float z = __builtin_fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * __expf(-z * z);  // erf(|x|/sqrt2)
+    return 0.5f * x * (1.0f + __builtin_copysignf(e, x));
+}
 
 // GEMM row -> row of an output buffer
 ADA_DEV long map_row(const IgemmDev& p, int map, uint32_t m) {
@@ -114,6 +126,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
         tn = logical - tm * p.tiles_n;
     }
     const int m0 = tm * BM, n0 = tn * BN;
+    unsigned long long t_entry = 0, t_first = 0, t_loop = 0;
+    if (p.dbg) t_entry = __builtin_amdgcn_s_memtime();
+    if (p.skew > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+        for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     // ---- per-thread staging addresses --------------------------------------------------
     const int srow = tid >> 3;                        // row inside a staging pass
@@ -142,8 +159,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
         b_ptr[it] = p.W + (long)n * p.K + gchunk * 8;
     }
 
-    auto stage = [&](int buf, int kt) {
-        long aoff;
+    // k-step kt -> element offsets of its A and W slabs (wave-uniform scalars)
+    auto slab_offsets = [&](int kt, long& aoff, long& boff) {
         if (p.a_mode == ADA_A_PLAIN) {
             aoff = (long)kt * BK;
         } else {
@@ -152,18 +169,23 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
             const int dy = tap / 3, dx = tap - dy * 3;
             aoff = ((long)dy * p.Wp + dx) * p.lda + (long)kc * BK;
         }
-        const long boff = (long)kt * BK;
+        boff = (long)kt * BK;
+    };
+    // issue the global->LDS copies of one quarter (part 0..3) of a stage; part < 0 issues everything
+    auto stage_part = [&](int buf, long aoff, long boff, int part) {
         char* sa = smem + buf * STAGE_BYTES + wave * 1024;
         char* sb = sa + A_BYTES;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[it] + aoff),
-                                             (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
+            if (part < 0 || (it & 3) == part)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[it] + aoff),
+                                                 (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[it] + boff),
-                                             (__attribute__((address_space(3))) void*)(sb + it * (NT * 16)), 16, 0, 0);
+            if (part < 0 || ((it + 2) & 3) == part)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[it] + boff),
+                                                 (__attribute__((address_space(3))) void*)(sb + it * (NT * 16)), 16, 0, 0);
         }
     };
 
@@ -182,30 +204,84 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
     const int b_row_off = A_BYTES + (wn * TJ * 32 + l31) * 128;
 
     const int nk = p.K / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const char* sbase = smem + cur * STAGE_BYTES;
+    {
+        long aoff, boff;
+        slab_offsets(0, aoff, boff);
+        stage_part(0, aoff, boff, -1);
+    }
+    if (p.sched == 0) {
+        // schedule 0: all copies of slab t+1 issued right after the barrier, compiler-scheduled fragment reads
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (p.dbg && kt == 0) t_first = __builtin_amdgcn_s_memtime();
+            if (kt + 1 < nk) {
+                long aoff, boff;
+                slab_offsets(kt + 1, aoff, boff);
+                stage_part(cur ^ 1, aoff, boff, -1);
+            }
+            const char* sbase = smem + cur * STAGE_BYTES;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int coff = ((2 * s + hi) ^ swz) * 16;
-            opx8 af[TI], bf[TJ];
+            for (int s = 0; s < 4; ++s) {
+                const int coff = ((2 * s + hi) ^ swz) * 16;
+                opx8 af[TI], bf[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) af[i] = *(const opx8*)(sbase + a_row_off + i * 32 * 128 + coff);
+                for (int i = 0; i < TI; ++i) af[i] = *(const opx8*)(sbase + a_row_off + i * 32 * 128 + coff);
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) bf[j] = *(const opx8*)(sbase + b_row_off + j * 32 * 128 + coff);
+                for (int j = 0; j < TJ; ++j) bf[j] = *(const opx8*)(sbase + b_row_off + j * 32 * 128 + coff);
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
+                for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+                    for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+            }
+        }
+    } else {
+        // schedule 1/2: fragments of sub-step s+1 are read while the MFMAs of sub-step s run (register double
+        // buffer), and the global->LDS copies of slab t+1 are spread over the four sub-steps instead of bunched
+        // behind the barrier; schedule 2 additionally raises the wave priority around each MFMA cluster.
+        const bool prio = p.sched >= 2;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const bool more = kt + 1 < nk;
+            long aoff = 0, boff = 0;
+            if (more) slab_offsets(kt + 1, aoff, boff);
+            const char* sbase = smem + cur * STAGE_BYTES;
+            opx8 af[2][TI], bf[2][TJ];
+            {
+                const int coff = (hi ^ swz) * 16;
+#pragma unroll
+                for (int i = 0; i < TI; ++i) af[0][i] = *(const opx8*)(sbase + a_row_off + i * 32 * 128 + coff);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) bf[0][j] = *(const opx8*)(sbase + b_row_off + j * 32 * 128 + coff);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (more) stage_part(cur ^ 1, aoff, boff, s);
+                if (s < 3) {
+                    const int coff = ((2 * (s + 1) + hi) ^ swz) * 16;
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) af[(s + 1) & 1][i] = *(const opx8*)(sbase + a_row_off + i * 32 * 128 + coff);
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) bf[(s + 1) & 1][j] = *(const opx8*)(sbase + b_row_off + j * 32 * 128 + coff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(af[s & 1][i], bf[s & 1][j], acc[i][j]);
+                if (prio) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
     // ---- epilogue: transpose through a wave-private LDS slab, then float4 per lane ----------------
-    __syncthreads();  // every wave is done reading the last stage before the slabs overwrite it
+    __syncthreads();
+    if (p.dbg) t_loop = __builtin_amdgcn_s_memtime();  // every wave is done reading the last stage before the slabs overwrite it
     constexpr int WCOLS = TJ * 32;                    // columns of this wave's tile
     float* slab = (float*)(smem + wave * (32 * WCOLS * 4));
     const int flags = p.flags;
@@ -247,24 +323,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
                 }
             }
         }
-        return;
-    } else {
-        constexpr int CG = WCOLS / 4;    // float4 column groups per row (8 or 16)
-        constexpr int RPI = 64 / CG;     // rows covered by one wave-wide float4 read (8 or 4)
+    } else if constexpr (EPI == EPI_TAIL) {
+        constexpr int CG = WCOLS / 4;
+        constexpr int RPI = 64 / CG;
         const int cg = lane % CG, rsub = lane / CG;
         const int n = nbase + 4 * cg;
-        const bool nval = n < p.N;       // N % 4 == 0 is checked on the host
-        float4 bias4 = make_float4(0, 0, 0, 0), gamma4 = make_float4(1, 1, 1, 1), tail4 = make_float4(0, 0, 0, 0);
+        const bool nval = n < p.N;
+        float4 bias4 = make_float4(0, 0, 0, 0), tail4 = make_float4(0, 0, 0, 0);
         if (nval) {
             if (flags & ADA_EP_BIAS) bias4 = *(const float4*)(p.bias + n);
-            if (flags & ADA_EP_GAMMA) gamma4 = *(const float4*)(p.gamma + n);
-            if constexpr (EPI == EPI_TAIL) tail4 = *(const float4*)(p.tail_w + n);
-        }
-        uint32_t sh_i = 0, sh_j = 0, sh_co = 0;
-        if constexpr (EPI == EPI_SHUFFLE) {
-            uint32_t ij;
-            fast_divmod((uint32_t)(nval ? n : 0), p.dShC, ij, sh_co);
-            fast_divmod(ij, p.dShS, sh_i, sh_j);
+            tail4 = *(const float4*)(p.tail_w + n);
         }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
@@ -276,68 +344,200 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
             for (int k = 0; k < 32 / RPI; ++k) {
                 const int row = k * RPI + rsub;
                 const int m = mbase + i * 32 + row;
-                float4 v = *(const float4*)(slab + row * WCOLS + 4 * cg);
-                v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-                if constexpr (EPI == EPI_TAIL) {
-                    float part = __builtin_fmaxf(v.x, 0.f) * tail4.x + __builtin_fmaxf(v.y, 0.f) * tail4.y +
-                                 __builtin_fmaxf(v.z, 0.f) * tail4.z + __builtin_fmaxf(v.w, 0.f) * tail4.w;
+                const float4 v = *(const float4*)(slab + row * WCOLS + 4 * cg);
+                float part = __builtin_fmaxf(v.x + bias4.x, 0.f) * tail4.x + __builtin_fmaxf(v.y + bias4.y, 0.f) * tail4.y +
+                             __builtin_fmaxf(v.z + bias4.z, 0.f) * tail4.z + __builtin_fmaxf(v.w + bias4.w, 0.f) * tail4.w;
 #pragma unroll
-                    for (int o = 1; o < CG; o <<= 1) part += __shfl_xor(part, o);
-                    if (cg == 0 && m < p.M) {
-                        float d = part + p.tail_b;
-                        if (p.tail_act == ADA_ACT_SIGMOID) d = 1.0f / (1.0f + __expf(-d));
-                        else if (p.tail_act == ADA_ACT_RELU) d = __builtin_fmaxf(d, 0.0f);
-                        p.out_f32[m] = d;
+                for (int o = 1; o < CG; o <<= 1) part += __shfl_xor(part, o);
+                if (cg == 0 && m < p.M) {
+                    float d = part + p.tail_b;
+                    if (p.tail_act == ADA_ACT_SIGMOID) d = 1.0f / (1.0f + __expf(-d));
+                    else if (p.tail_act == ADA_ACT_RELU) d = __builtin_fmaxf(d, 0.0f);
+                    p.out_f32[m] = d;
+                }
+            }
+        }
+    } else if (!p.out_f32 && !(flags & ADA_EP_RESIDUAL) && (p.ldo_op & 7) == 0 && (EPI != EPI_SHUFFLE || (p.shuffle_c & 7) == 0)) {
+        // ---- operand-only output: 8 columns per lane -> one 16-byte store per row segment ----------------
+        constexpr int CG = WCOLS / 8;    // 8-column groups per row (4 or 8)
+        constexpr int RPI = 64 / CG;     // rows per wave-wide access (16 or 8)
+        const int cg = lane % CG, rsub = lane / CG;
+        const int n = nbase + 8 * cg;
+        const bool nval = n < p.N;       // N % 8 == 0 on this path (checked below via nval of the second half)
+        const bool nval2 = n + 4 < p.N;
+        float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, g0 = make_float4(1, 1, 1, 1), g1 = g0;
+        if (flags & ADA_EP_BIAS) {
+            if (nval) b0 = *(const float4*)(p.bias + n);
+            if (nval2) b1 = *(const float4*)(p.bias + n + 4);
+        }
+        if (flags & ADA_EP_GAMMA) {
+            if (nval) g0 = *(const float4*)(p.gamma + n);
+            if (nval2) g1 = *(const float4*)(p.gamma + n + 4);
+        }
+        uint32_t sh_i = 0, sh_j = 0, sh_co = 0;
+        if constexpr (EPI == EPI_SHUFFLE) {
+            uint32_t ij;
+            fast_divmod((uint32_t)(nval ? n : 0), p.dShC, ij, sh_co);
+            fast_divmod(ij, p.dShS, sh_i, sh_j);
+        }
+        const bool relu = (flags & ADA_EP_RELU_OP) != 0;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[crow32(r, hi) * WCOLS + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+            for (int k = 0; k < 32 / RPI; ++k) {
+                const int row = k * RPI + rsub;
+                const int m = mbase + i * 32 + row;
+                float4 v0 = *(const float4*)(slab + row * WCOLS + 8 * cg);
+                float4 v1 = *(const float4*)(slab + row * WCOLS + 8 * cg + 4);
+                v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
+                v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
+                if constexpr (EPI == EPI_GELU) {
+                    v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
+                    v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
+                }
+                v0.x *= g0.x; v0.y *= g0.y; v0.z *= g0.z; v0.w *= g0.w;
+                v1.x *= g1.x; v1.y *= g1.y; v1.z *= g1.z; v1.w *= g1.w;
+                if (relu) {
+                    v0.x = __builtin_fmaxf(v0.x, 0.f); v0.y = __builtin_fmaxf(v0.y, 0.f); v0.z = __builtin_fmaxf(v0.z, 0.f); v0.w = __builtin_fmaxf(v0.w, 0.f);
+                    v1.x = __builtin_fmaxf(v1.x, 0.f); v1.y = __builtin_fmaxf(v1.y, 0.f); v1.z = __builtin_fmaxf(v1.z, 0.f); v1.w = __builtin_fmaxf(v1.w, 0.f);
+                }
+                if (m < p.M && nval) {
+                    long orow;
+                    int ocol = n;
+                    if constexpr (EPI == EPI_SHUFFLE) {
+                        uint32_t sb, rem, sy, sx;
+                        fast_divmod((uint32_t)m, p.dMapHW, sb, rem);
+                        fast_divmod(rem, p.dMapW, sy, sx);
+                        orow = ((long)sb * (p.shuffle_s * p.map_h + 2) + (p.shuffle_s * sy + sh_i + 1)) * (p.shuffle_s * p.map_w + 2) +
+                               (p.shuffle_s * sx + sh_j + 1);
+                        ocol = (int)sh_co;
+                    } else {
+                        orow = map_row(p, p.map_op, (uint32_t)m);
                     }
-                } else {
-                    if (m < p.M && nval) {
-                        if constexpr (EPI == EPI_GELU) {
-                            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
-                        }
-                        v.x *= gamma4.x; v.y *= gamma4.y; v.z *= gamma4.z; v.w *= gamma4.w;
-                        long frow = 0;
-                        if (p.out_f32 || (flags & ADA_EP_RESIDUAL)) frow = map_row(p, p.map_f32, (uint32_t)m);
-                        if (flags & ADA_EP_RESIDUAL) {
-                            long rrow = frow;
-                            if (p.res_row_mod > 0) {
-                                uint32_t qq, rr;
-                                fast_divmod((uint32_t)m, p.dResMod, qq, rr);
-                                rrow = (long)rr + p.res_row_off;
-                            }
-                            const float4 rv = *(const float4*)(p.res + rrow * p.ldr + n);
-                            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                        }
-                        if (p.out_f32) {
-                            float4 w = v;
-                            if (flags & ADA_EP_RELU_F32) {
-                                w.x = __builtin_fmaxf(w.x, 0.f); w.y = __builtin_fmaxf(w.y, 0.f);
-                                w.z = __builtin_fmaxf(w.z, 0.f); w.w = __builtin_fmaxf(w.w, 0.f);
-                            }
-                            *(float4*)(p.out_f32 + frow * p.ldo_f32 + n) = w;
-                        }
-                        if (p.out_op) {
-                            if (flags & ADA_EP_RELU_OP) {
-                                v.x = __builtin_fmaxf(v.x, 0.f); v.y = __builtin_fmaxf(v.y, 0.f);
-                                v.z = __builtin_fmaxf(v.z, 0.f); v.w = __builtin_fmaxf(v.w, 0.f);
-                            }
-                            long orow;
-                            int ocol = n;
-                            if constexpr (EPI == EPI_SHUFFLE) {
-                                uint32_t sb, rem, sy, sx;
-                                fast_divmod((uint32_t)m, p.dMapHW, sb, rem);
-                                fast_divmod(rem, p.dMapW, sy, sx);
-                                orow = ((long)sb * (p.shuffle_s * p.map_h + 2) + (p.shuffle_s * sy + sh_i + 1)) *
-                                           (p.shuffle_s * p.map_w + 2) + (p.shuffle_s * sx + sh_j + 1);
-                                ocol = (int)sh_co;
-                            } else {
-                                orow = map_row(p, p.map_op, (uint32_t)m);
-                            }
-                            *(opx4*)(p.out_op + orow * p.ldo_op + ocol) = pack4(v);
-                        }
+                    op_t* dst = p.out_op + orow * p.ldo_op + ocol;
+                    if (nval2) {
+                        const opx4 lo = pack4(v0), hi4 = pack4(v1);
+                        opx8 o;
+                        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+                        o[4] = hi4[0]; o[5] = hi4[1]; o[6] = hi4[2]; o[7] = hi4[3];
+                        *(opx8*)dst = o;
+                    } else {
+                        *(opx4*)dst = pack4(v0);
                     }
                 }
             }
         }
+    } else {
+        // ---- fp32 output and/or residual: 4 columns per lane; the residual loads of a whole 32-row pass are issued
+        //      together (clamped, unconditional) one pass ahead, so their HBM latency hides behind the LDS transpose ----
+        constexpr int CG = WCOLS / 4;    // float4 column groups per row (8 or 16)
+        constexpr int RPI = 64 / CG;     // rows covered by one wave-wide float4 read (8 or 4)
+        constexpr int NKI = 32 / RPI;
+        const int cg = lane % CG, rsub = lane / CG;
+        const int n = nbase + 4 * cg;
+        const bool nval = n < p.N;       // N % 4 == 0 is checked on the host
+        const int nc = nval ? n : 0;
+        float4 bias4 = make_float4(0, 0, 0, 0), gamma4 = make_float4(1, 1, 1, 1);
+        if (flags & ADA_EP_BIAS) bias4 = *(const float4*)(p.bias + nc);
+        if (flags & ADA_EP_GAMMA) gamma4 = *(const float4*)(p.gamma + nc);
+        uint32_t sh_i = 0, sh_j = 0, sh_co = 0;
+        if constexpr (EPI == EPI_SHUFFLE) {
+            uint32_t ij;
+            fast_divmod((uint32_t)nc, p.dShC, ij, sh_co);
+            fast_divmod(ij, p.dShS, sh_i, sh_j);
+        }
+        const bool has_res = (flags & ADA_EP_RESIDUAL) != 0;
+        auto res_ptr = [&](int i, int k) -> const float* {
+            int m = mbase + i * 32 + k * RPI + rsub;
+            if (m >= p.M) m = p.M - 1;
+            long rrow;
+            if (p.res_row_mod > 0) {
+                uint32_t qq, rr;
+                fast_divmod((uint32_t)m, p.dResMod, qq, rr);
+                rrow = (long)rr + p.res_row_off;
+            } else {
+                rrow = map_row(p, p.map_f32, (uint32_t)m);
+            }
+            return p.res + rrow * p.ldr + nc;
+        };
+        float4 rcur[NKI], rnext[NKI];
+#pragma unroll
+        for (int k = 0; k < NKI; ++k) rcur[k] = rnext[k] = make_float4(0, 0, 0, 0);
+        if (has_res) {
+#pragma unroll
+            for (int k = 0; k < NKI; ++k) rcur[k] = *(const float4*)res_ptr(0, k);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            if (has_res && i + 1 < TI) {
+#pragma unroll
+                for (int k = 0; k < NKI; ++k) rnext[k] = *(const float4*)res_ptr(i + 1, k);
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[crow32(r, hi) * WCOLS + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+            for (int k = 0; k < NKI; ++k) {
+                const int row = k * RPI + rsub;
+                const int m = mbase + i * 32 + row;
+                float4 v = *(const float4*)(slab + row * WCOLS + 4 * cg);
+                v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                if constexpr (EPI == EPI_GELU) {
+                    v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                }
+                v.x = v.x * gamma4.x + rcur[k].x; v.y = v.y * gamma4.y + rcur[k].y;
+                v.z = v.z * gamma4.z + rcur[k].z; v.w = v.w * gamma4.w + rcur[k].w;
+                if (m < p.M && nval) {
+                    if (p.out_f32) {
+                        const long frow = map_row(p, p.map_f32, (uint32_t)m);
+                        float4 w = v;
+                        if (flags & ADA_EP_RELU_F32) {
+                            w.x = __builtin_fmaxf(w.x, 0.f); w.y = __builtin_fmaxf(w.y, 0.f);
+                            w.z = __builtin_fmaxf(w.z, 0.f); w.w = __builtin_fmaxf(w.w, 0.f);
+                        }
+                        *(float4*)(p.out_f32 + frow * p.ldo_f32 + n) = w;
+                    }
+                    if (p.out_op) {
+                        if (flags & ADA_EP_RELU_OP) {
+                            v.x = __builtin_fmaxf(v.x, 0.f); v.y = __builtin_fmaxf(v.y, 0.f);
+                            v.z = __builtin_fmaxf(v.z, 0.f); v.w = __builtin_fmaxf(v.w, 0.f);
+                        }
+                        long orow;
+                        int ocol = n;
+                        if constexpr (EPI == EPI_SHUFFLE) {
+                            uint32_t sb, rem, sy, sx;
+                            fast_divmod((uint32_t)m, p.dMapHW, sb, rem);
+                            fast_divmod(rem, p.dMapW, sy, sx);
+                            orow = ((long)sb * (p.shuffle_s * p.map_h + 2) + (p.shuffle_s * sy + sh_i + 1)) *
+                                       (p.shuffle_s * p.map_w + 2) + (p.shuffle_s * sx + sh_j + 1);
+                            ocol = (int)sh_co;
+                        } else {
+                            orow = map_row(p, p.map_op, (uint32_t)m);
+                        }
+                        *(opx4*)(p.out_op + orow * p.ldo_op + ocol) = pack4(v);
+                    }
+                }
+            }
+            if (has_res) {
+#pragma unroll
+                for (int k = 0; k < NKI; ++k) rcur[k] = rnext[k];
+            }
+        }
+    }
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = p.dbg + (long)blockIdx.x * 6;
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        d[0] = t_entry; d[1] = t_first; d[2] = t_loop; d[3] = __builtin_amdgcn_s_memtime();
+        d[4] = ((unsigned long long)xcc << 32) | hwid; d[5] = ((unsigned long long)tm << 32) | (unsigned)tn;
     }
 }
 
@@ -384,6 +584,10 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force) {
 }
 
 }  // namespace
+
+static unsigned long long* g_dbg = nullptr;
+// debug hook (not part of the stable ABI): device buffer of 6 x u64 per workgroup, or NULL to disable
+extern "C" void ada_debug_set_timestamps(void* dev_buf) { g_dbg = (unsigned long long*)dev_buf; }
 
 extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     ADA_REQUIRE(a != nullptr, ADA_EINVAL, "ada_igemm: null args");
@@ -466,11 +670,18 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.cps = (int)(a->lda / BK);
     d.tiles_m = d.tiles_n = 0;
 
-    static int force = -2;
+    static int force = -2, sched = 0, skew = 0;
     if (force == -2) {
         const char* e = getenv("ADA_IGEMM_TILE");
         force = e ? atoi(e) : -1;
+        const char* sc = getenv("ADA_IGEMM_SCHED");
+        sched = sc ? atoi(sc) : 0;
+        const char* sk = getenv("ADA_IGEMM_SKEW");
+        skew = sk ? atoi(sk) : 0;
     }
+    d.sched = sched;
+    d.skew = skew;
+    d.dbg = g_dbg;
     hipStream_t s = (hipStream_t)stream;
     if (tail) return launch_epi<EPI_TAIL>(d, s, a->N <= 32 ? 0 : 1);
     if (swiglu) return launch_epi<EPI_SWIGLU>(d, s, force);

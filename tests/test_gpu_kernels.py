@@ -31,7 +31,7 @@ def test_selftest_fragment_layouts(hip):
     assert hip.selftest() == 0, hip.load().ada_last_error()
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (128, 128, 64), (1, 1, 64), (2740, 1152, 384), (257, 48, 192), (515, 32, 128)])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (128, 128, 64), (1, 4, 64), (2740, 1152, 384), (257, 48, 192), (515, 32, 128)])
 def test_igemm_plain_bias(hip, M, N, K):
     op = _op(hip)
     A = _rand(M, K, seed=1).to(op).to(DEV)

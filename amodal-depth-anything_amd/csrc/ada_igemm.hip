@@ -126,7 +126,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
         tn = logical - tm * p.tiles_n;
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    unsigned long long t_entry = 0, t_first = 0, t_loop = 0;
+    unsigned long long t_entry = 0, t_first = 0, t_loop = 0, t_vm = 0, t_bar = 0;
     if (p.dbg) t_entry = __builtin_amdgcn_s_memtime();
     if (p.skew > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
         for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(127);
@@ -209,12 +209,85 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
         slab_offsets(0, aoff, boff);
         stage_part(0, aoff, boff, -1);
     }
-    if (p.sched == 0) {
+    if (NWAVES == 8 && p.sched == 3) {
+        // schedule 3 ("ping-pong"): the two waves that share a SIMD (wave w and w+4) run half a k-step apart.  Each
+        // k-step has two barrier intervals; in one of them a wave only moves data (P1: first fragment reads, and for
+        // the late group its global->LDS copies), in the other it issues its 32 MFMAs (P2).  Group 0 (waves 0-3) is in
+        // P2 while group 1 (waves 4-7) is in P1 and vice versa, so the matrix pipe always has one wave feeding it.
+        //   physical barrier #:   1        2        3        4
+        //   group 0:        P1(0) | P2(0) | P1(1) | P2(1) | ...
+        //   group 1:        (x)   | P1(0) | P2(0) | P1(1) | ...
+        // LDS hazards: slab t+1 is copied into the buffer of slab t-1.  Group 0 issues its copies inside P2(t) (group 1
+        // finished P2(t-1) at the barrier before), group 1 at the start of its P1(t) (same interval); both wait for
+        // their own copies (vmcnt(0)) before the barrier that ends that interval, after which group 0 starts P1(t+1).
+        const int grp = wave >> 2;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (p.dbg) t_first = __builtin_amdgcn_s_memtime();
+        if (grp == 1) __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < nk;
+            long aoff = 0, boff = 0;
+            if (more) slab_offsets(kt + 1, aoff, boff);
+            const char* sbase = smem + cur * STAGE_BYTES;
+            // ---- P1: data movement only
+            if (grp == 1 && more) stage_part(cur ^ 1, aoff, boff, -1);
+            opx8 af[2][TI], bf[2][TJ];
+            {
+                const int coff = (hi ^ swz) * 16;
+#pragma unroll
+                for (int i = 0; i < TI; ++i) af[0][i] = *(const opx8*)(sbase + a_row_off + i * 32 * 128 + coff);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) bf[0][j] = *(const opx8*)(sbase + b_row_off + j * 32 * 128 + coff);
+            }
+            if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- P2: MFMAs (group 0 also issues its copies of slab t+1 in the first two sub-steps)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (grp == 0 && more && s < 2) {
+                    stage_part(cur ^ 1, aoff, boff, 2 * s);
+                    stage_part(cur ^ 1, aoff, boff, 2 * s + 1);
+                }
+                if (s < 3) {
+                    const int coff = ((2 * (s + 1) + hi) ^ swz) * 16;
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) af[(s + 1) & 1][i] = *(const opx8*)(sbase + a_row_off + i * 32 * 128 + coff);
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) bf[(s + 1) & 1][j] = *(const opx8*)(sbase + b_row_off + j * 32 * 128 + coff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(af[s & 1][i], bf[s & 1][j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+    } else if (p.sched == 0) {
         // schedule 0: all copies of slab t+1 issued right after the barrier, compiler-scheduled fragment reads
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
+            unsigned long long tw0 = 0, tw1 = 0;
+            if (p.dbg) tw0 = __builtin_amdgcn_s_memtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (p.dbg) tw1 = __builtin_amdgcn_s_memtime();
             __syncthreads();
+            if (p.dbg) {
+                const unsigned long long tw2 = __builtin_amdgcn_s_memtime();
+                t_vm += tw1 - tw0;
+                t_bar += tw2 - tw1;
+            }
             if (p.dbg && kt == 0) t_first = __builtin_amdgcn_s_memtime();
             if (kt + 1 < nk) {
                 long aoff, boff;
@@ -531,13 +604,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
     }
     if (p.dbg && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* d = p.dbg + (long)blockIdx.x * 6;
+        unsigned long long* d = p.dbg + (long)blockIdx.x * 8;
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         d[0] = t_entry; d[1] = t_first; d[2] = t_loop; d[3] = __builtin_amdgcn_s_memtime();
         d[4] = ((unsigned long long)xcc << 32) | hwid; d[5] = ((unsigned long long)tm << 32) | (unsigned)tn;
+        d[6] = t_vm; d[7] = t_bar;
     }
 }
 
@@ -586,7 +660,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force) {
 }  // namespace
 
 static unsigned long long* g_dbg = nullptr;
-// debug hook (not part of the stable ABI): device buffer of 6 x u64 per workgroup, or NULL to disable
+// debug hook (not part of the stable ABI): device buffer of 8 x u64 per workgroup, or NULL to disable
 extern "C" void ada_debug_set_timestamps(void* dev_buf) { g_dbg = (unsigned long long*)dev_buf; }
 
 extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {

@@ -1,0 +1,256 @@
+"""Stand-alone functional forms of the reference's L1 operators on top of libada_hip.
+
+These back the ``forward`` methods of the individual nn.Modules (Attention, Mlp, PatchEmbed, DPTHead ...), so each
+piece of the reference's module surface works on its own, computing in the same HIP kernels as the fused engine.
+They take/return the reference's tensor layouts (fp32, [B,N,D] tokens, NCHW feature maps) and therefore pay for
+layout changes and operand packing on every call -- torch is used for that plumbing (reshape / permute / pad / dtype
+cast) only; every contraction, normalisation, softmax and resample runs in a HIP kernel.  The whole-model path
+(``hip_ext.engine``) packs weights once and keeps activations in kernel-native layouts instead.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import (A_CONV3, ACT_NONE, ACT_RELU, ACT_SIGMOID, EP_BIAS, EP_GELU, EP_RELU_OP, EP_RESIDUAL, EP_SWIGLU, EP_TAIL,
+               MAP_PAD, MAP_PLAIN, MAP_SHUFFLE, HipExtError)
+from . import attention as k_attention
+from . import bilinear as k_bilinear
+from . import igemm as k_igemm
+from . import layernorm as k_layernorm
+from . import operand_dtype
+from . import patchify as k_patchify
+
+
+def _r64(c):
+    return (c + 63) // 64 * 64
+
+
+def _need_cuda(t, name):
+    if not t.is_cuda:
+        raise HipExtError(f"{name}: expected a tensor on a HIP device (the HIP path has no CPU fallback)")
+
+
+def _as_operand_rows(x2d):
+    """[M, K] (fp32 or operand type) -> contiguous operand-typed [M, r64(K)]."""
+    op = operand_dtype()
+    M, K = x2d.shape
+    if x2d.dtype == op and K % 64 == 0 and x2d.is_contiguous():
+        return x2d
+    out = torch.zeros(M, _r64(K), dtype=op, device=x2d.device)
+    out[:, :K] = x2d
+    return out
+
+
+def _pack_rows(w2d):
+    op = operand_dtype()
+    N, K = w2d.shape
+    out = torch.zeros(N, _r64(K), dtype=op, device=w2d.device)
+    out[:, :K] = w2d
+    return out
+
+
+def linear(x, weight, bias=None, gelu=False, out_operand=False):
+    """nn.Linear (+ optional exact GELU).  x: [..., K] fp32 or operand-typed; returns fp32 unless out_operand."""
+    _need_cuda(x, "linear input")
+    lead, K = x.shape[:-1], x.shape[-1]
+    N = weight.shape[0]
+    A = _as_operand_rows(x.reshape(-1, K))
+    W = _pack_rows(weight.detach().float())
+    M = A.shape[0]
+    flags = (EP_BIAS if bias is not None else 0) | (EP_GELU if gelu else 0)
+    b = None if bias is None else bias.detach().float().contiguous()
+    if N % 4:
+        raise HipExtError("linear: out_features must be a multiple of 4")
+    if out_operand:
+        out = torch.empty(M, N, dtype=operand_dtype(), device=x.device)
+        k_igemm(M=M, N=N, K=A.shape[1], A=A, lda=A.shape[1], W=W, bias=b, flags=flags, out_op=out, ldo_op=N)
+    else:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        k_igemm(M=M, N=N, K=A.shape[1], A=A, lda=A.shape[1], W=W, bias=b, flags=flags, out_f32=out, ldo_f32=N)
+    return out.reshape(*lead, N)
+
+
+def swiglu_linear(x, w12, b12):
+    """SwiGLU first half: silu(x1) * x2 with [x1, x2] = w12(x) (reference swiglu_ffn.py:30-32); operand-typed result."""
+    _need_cuda(x, "swiglu input")
+    lead, K = x.shape[:-1], x.shape[-1]
+    hid = w12.shape[0] // 2
+    idx = torch.arange(hid, device=w12.device).reshape(-1, 32)
+    order = torch.stack([idx, idx + hid], dim=1).reshape(-1)
+    A = _as_operand_rows(x.reshape(-1, K))
+    W = _pack_rows(w12.detach().float()[order])
+    b = None if b12 is None else b12.detach().float()[order].contiguous()
+    M = A.shape[0]
+    out = torch.empty(M, hid, dtype=operand_dtype(), device=x.device)
+    k_igemm(M=M, N=2 * hid, K=A.shape[1], A=A, lda=A.shape[1], W=W, bias=b, flags=(EP_BIAS if b is not None else 0) | EP_SWIGLU,
+            out_op=out, ldo_op=hid)
+    return out.reshape(*lead, hid)
+
+
+def layer_norm(x, weight, bias, eps):
+    """LayerNorm over the last dim, fp32 in / fp32 out."""
+    _need_cuda(x, "layer_norm input")
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D).float().contiguous()
+    out = torch.empty_like(x2)
+    k_layernorm(x2, D, x2.shape[0], D, weight.detach().float().contiguous(), bias.detach().float().contiguous(), float(eps),
+                out_f32=out, ld_f32=D)
+    return out.reshape(x.shape)
+
+
+def scale_channels(x, gamma):
+    """LayerScale: x * gamma (a broadcast multiply; inside the engine it is fused into the GEMM epilogue)."""
+    return x * gamma
+
+
+def self_attention(x, qkv_w, qkv_b, proj_w, proj_b, num_heads):
+    """Attention.forward (reference attention.py:49-62): qkv linear -> fused softmax(q k^T / sqrt(d)) v -> proj."""
+    _need_cuda(x, "attention input")
+    B, N, C = x.shape
+    if C // num_heads != 64:
+        raise HipExtError("self_attention: the fused kernel is built for head_dim 64 (every DINOv2 size)")
+    w = qkv_w.detach().float().clone()
+    w[:C] *= 0.125
+    b = None
+    if qkv_b is not None:
+        b = qkv_b.detach().float().clone()
+        b[:C] *= 0.125
+    qkv = linear(x, w, b, out_operand=True).reshape(B * N, 3 * C)
+    o = torch.empty(B * N, C, dtype=operand_dtype(), device=x.device)
+    k_attention(qkv, o, B, N, num_heads)
+    return linear(o.reshape(B, N, C), proj_w, proj_b)
+
+
+def patch_embed(x, weight, bias):
+    """PatchEmbed conv (k = stride = 14) as patchify + GEMM; x: [B,C,H,W] fp32 -> [B, Np, D] fp32."""
+    _need_cuda(x, "patch_embed input")
+    B, C, H, W = x.shape
+    if weight.shape[-1] != 14 or weight.shape[-2] != 14:
+        raise HipExtError("patch_embed: the patchify kernel is built for 14x14 patches")
+    D = weight.shape[0]
+    x = x.float().contiguous()
+    K = C * 196
+    ld = _r64(K)
+    P = B * (H // 14) * (W // 14)
+    A = torch.empty(P, ld, dtype=operand_dtype(), device=x.device)
+    # the kernel's first three channels are "rgb", the rest "guide": split any channel count accordingly
+    if C >= 3:
+        k_patchify(x[:, :3].contiguous(), x[:, 3:].contiguous() if C > 3 else None, B, C - 3, H, W, None, None, A, ld)
+    else:
+        xp = torch.cat([x, torch.zeros(B, 3 - C, H, W, device=x.device)], 1)
+        A3 = torch.empty(P, _r64(588), dtype=operand_dtype(), device=x.device)
+        k_patchify(xp, None, B, 0, H, W, None, None, A3, A3.shape[1])
+        A.zero_()
+        A[:, :K] = A3[:, :K]
+    out = torch.empty(P, D, dtype=torch.float32, device=x.device)
+    k_igemm(M=P, N=D, K=ld, A=A, lda=ld, W=_pack_rows(weight.detach().float().reshape(D, K)),
+            bias=None if bias is None else bias.detach().float().contiguous(), flags=EP_BIAS if bias is not None else 0,
+            out_f32=out, ldo_f32=D)
+    return out.reshape(B, -1, D)
+
+
+def _to_padded_nhwc(x):
+    B, C, H, W = x.shape
+    cp = _r64(C)
+    buf = torch.zeros(B, H + 2, W + 2, cp, dtype=operand_dtype(), device=x.device)
+    buf[:, 1:-1, 1:-1, :C] = x.permute(0, 2, 3, 1)
+    return buf
+
+
+def _pack_conv3(w):
+    co, ci = w.shape[:2]
+    cp = _r64(ci)
+    p = torch.zeros(co, 3, 3, cp, dtype=operand_dtype(), device=w.device)
+    p[..., :ci] = w.permute(0, 2, 3, 1)
+    return p.reshape(co, 9 * cp)
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, relu_input=False):
+    """nn.Conv2d for the two shapes the DPT head uses: 1x1/s1/p0 and 3x3/(s1|s2)/p1.  NCHW fp32 in/out."""
+    _need_cuda(x, "conv2d input")
+    B, C, H, W = x.shape
+    Co, _, kh, kw = weight.shape
+    if relu_input:
+        x = torch.relu(x)
+    b = None if bias is None else bias.detach().float().contiguous()
+    flags = EP_BIAS if b is not None else 0
+    if Co % 4:
+        raise HipExtError("conv2d: out_channels must be a multiple of 4 (use conv_tail for the 32->1 head)")
+    if (kh, kw) == (1, 1) and stride == 1 and padding == 0:
+        A = _as_operand_rows(x.permute(0, 2, 3, 1).reshape(-1, C))
+        out = torch.empty(A.shape[0], Co, dtype=torch.float32, device=x.device)
+        k_igemm(M=A.shape[0], N=Co, K=A.shape[1], A=A, lda=A.shape[1], W=_pack_rows(weight.detach().float().reshape(Co, C)), bias=b,
+                flags=flags, out_f32=out, ldo_f32=Co)
+        return out.reshape(B, H, W, Co).permute(0, 3, 1, 2).contiguous()
+    if (kh, kw) == (3, 3) and padding == 1 and stride in (1, 2):
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        xin = _to_padded_nhwc(x.float())
+        cp = xin.shape[3]
+        out = torch.empty(B * Ho * Wo, Co, dtype=torch.float32, device=x.device)
+        k_igemm(M=B * Ho * Wo, N=Co, K=9 * cp, A=xin, lda=cp, W=_pack_conv3(weight.detach().float()), a_mode=A_CONV3,
+                conv=(Ho, Wo, H + 2, W + 2, stride), bias=b, flags=flags, out_f32=out, ldo_f32=Co)
+        return out.reshape(B, Ho, Wo, Co).permute(0, 3, 1, 2).contiguous()
+    raise HipExtError(f"conv2d: unsupported geometry k={kh}x{kw} stride={stride} padding={padding}")
+
+
+def conv_transpose2d(x, weight, bias, stride):
+    """nn.ConvTranspose2d with kernel == stride (non-overlapping): GEMM + pixel shuffle.  NCHW fp32 in/out."""
+    _need_cuda(x, "conv_transpose2d input")
+    B, Ci, H, W = x.shape
+    Co, s = weight.shape[1], int(stride)
+    if weight.shape[2] != s or weight.shape[3] != s or Co % 8:
+        raise HipExtError("conv_transpose2d: kernel must equal stride and out_channels be a multiple of 8")
+    A = _as_operand_rows(x.permute(0, 2, 3, 1).reshape(-1, Ci))
+    Wt = _pack_rows(weight.detach().float().permute(2, 3, 1, 0).reshape(s * s * Co, Ci))
+    out = torch.zeros(B, s * H + 2, s * W + 2, Co, dtype=operand_dtype(), device=x.device)
+    bb = torch.zeros(Co, device=x.device) if bias is None else bias.detach().float()
+    k_igemm(M=B * H * W, N=s * s * Co, K=A.shape[1], A=A, lda=A.shape[1], W=Wt, bias=bb.repeat(s * s).contiguous(), flags=EP_BIAS,
+            out_op=out, ldo_op=Co, map_op=MAP_SHUFFLE, map_h=H, map_w=W, shuffle_s=s, shuffle_c=Co)
+    return out[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float().contiguous()
+
+
+def residual_conv_unit(x, w1, b1, w2, b2):
+    """ResidualConvUnit (reference blocks.py:57-80) with ReLU / residual fused into the conv epilogues."""
+    _need_cuda(x, "residual_conv_unit input")
+    B, C, H, W = x.shape
+    x = x.float()
+    cp = _r64(C)
+    xr = _to_padded_nhwc(torch.relu(x))
+    mid = torch.zeros(B, H + 2, W + 2, cp, dtype=operand_dtype(), device=x.device)
+    geom = (H, W, H + 2, W + 2, 1)
+    k_igemm(M=B * H * W, N=C, K=9 * cp, A=xr, lda=cp, W=_pack_conv3(w1.detach().float()), a_mode=A_CONV3, conv=geom,
+            bias=b1.detach().float().contiguous(), flags=EP_BIAS | EP_RELU_OP, out_op=mid, ldo_op=cp, map_op=MAP_PAD, map_h=H, map_w=W)
+    res = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous()
+    out = torch.empty_like(res)
+    k_igemm(M=B * H * W, N=C, K=9 * cp, A=mid, lda=cp, W=_pack_conv3(w2.detach().float()), a_mode=A_CONV3, conv=geom,
+            bias=b2.detach().float().contiguous(), res=res, ldr=C, flags=EP_BIAS | EP_RESIDUAL, out_f32=out, ldo_f32=C)
+    return out.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+
+
+def interpolate_bilinear_ac(x, size):
+    """F.interpolate(mode='bilinear', align_corners=True) on NCHW fp32."""
+    _need_cuda(x, "interpolate input")
+    B, C, H, W = x.shape
+    ho, wo = int(size[0]), int(size[1])
+    if C % 4:
+        raise HipExtError("interpolate_bilinear_ac: channels must be a multiple of 4")
+    src = x.float().permute(0, 2, 3, 1).reshape(-1, C).contiguous()
+    out = torch.empty(B * ho * wo, C, dtype=torch.float32, device=x.device)
+    k_bilinear(src, C, B, H, W, ho, wo, C, out_f32=out, ld_f32=C)
+    return out.reshape(B, ho, wo, C).permute(0, 3, 1, 2).contiguous()
+
+
+def conv_tail(x, w0, b0, w2, b2, final_act):
+    """output_conv2: conv3x3(C->32) + ReLU + conv1x1(32->1) + Sigmoid/ReLU/identity in one launch
+    (reference DA2/dpt.py:146-151, RAW dpt.py:109-115).  NCHW fp32 in, [B,1,H,W] fp32 out."""
+    _need_cuda(x, "conv_tail input")
+    B, C, H, W = x.shape
+    xin = _to_padded_nhwc(x.float())
+    cp = xin.shape[3]
+    out = torch.empty(B, 1, H, W, dtype=torch.float32, device=x.device)
+    act = {"sigmoid": ACT_SIGMOID, "relu": ACT_RELU, "none": ACT_NONE}[final_act]
+    k_igemm(M=B * H * W, N=w0.shape[0], K=9 * cp, A=xin, lda=cp, W=_pack_conv3(w0.detach().float()), a_mode=A_CONV3,
+            conv=(H, W, H + 2, W + 2, 1), bias=b0.detach().float().contiguous(), flags=EP_BIAS | EP_TAIL, out_f32=out, ldo_f32=1,
+            tail_w=w2.detach().float().reshape(-1).contiguous(), tail_b=float(b2.detach().float().reshape(-1)[0].item()), tail_act=act)
+    return out

@@ -31,6 +31,22 @@ def build_product_model(case):
     return DepthAnythingV2(encoder=case["encoder"], features=case["features"], out_channels=case["out_channels"]).eval()
 
 
+def schema_key(case):
+    if case["kind"] == "raw":
+        return f"raw/{case['encoder']}"
+    return f"amodal/{case['encoder']}/{case['guide_type']}"
+
+
+def schema_state_dict(case, meta=None, seed=0):
+    """Synthetic state_dict built from the reference's key/shape schema fixture (no nn.Module construction: fast)."""
+    schema = json.load(open(os.path.join(GOLDEN_DIR, "state_dict_schema.json")))[schema_key(case)]
+    sd = {k: torch.zeros(shape) for k, shape in schema.items()}
+    fill_state_dict_(sd, seed)
+    if meta is not None:
+        sd[meta["final_bias_key"]] = torch.full_like(sd[meta["final_bias_key"]], meta["final_bias"])
+    return sd
+
+
 def synth_state_dict(model, meta=None, seed=0):
     """fp32 CPU state_dict with the deterministic synthetic fill (+ the fixture's logit-centring bias)."""
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}

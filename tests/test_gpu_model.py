@@ -76,3 +76,38 @@ def test_cpu_tensors_are_rejected(hip):
         model(x, guide_rgb=None, guide_mask=mask, observation=obs)
     with pytest.raises(AssertionError, match="not a multiple of patch"):
         model(torch.zeros(1, 3, 100, 98).cuda(), guide_rgb=None, guide_mask=torch.zeros(1, 1, 100, 98).cuda(), observation=None)
+
+
+def test_module_by_module_path_matches_oracle(hip):
+    """The stand-alone L1 modules (PatchEmbed, Block, Attention, Mlp, DPTHead, FeatureFusionBlock ...) composed the way the
+    reference composes them (get_intermediate_layers -> DPTHead.forward) agree with the oracle too."""
+    _, meta = load_golden("vits_g_image_mask_observation")
+    case = meta["case"]
+    model = build_product_model(case)
+    sd = synth_state_dict(model, meta)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda()
+    x, grgb, mask, obs = case_inputs(case)
+    ref = oracle_forward(sd, case, x, grgb, mask, obs)
+    with torch.no_grad():
+        guide = model.build_guide(grgb.cuda(), mask.cuda(), obs.cuda())
+        out = model.encoder.forward_modular(x.cuda(), guide).cpu()
+        fused = model(x.cuda(), guide_rgb=grgb.cuda(), guide_mask=mask.cuda(), observation=obs.cuda()).cpu()
+    e1, e2 = rel_l1(out, ref), rel_l1(fused, ref)
+    print(f"modular path rel-L1 = {e1:.3e}; fused engine rel-L1 = {e2:.3e}")
+    assert e1 <= TOL and e2 <= TOL
+
+
+def test_raw_swiglu_module_path(hip):
+    """ViT-G style SwiGLU block through the module-level functional path vs torch."""
+    import torch.nn.functional as F
+    from src.models.amodalsynthdrive.depth_anything_v2.dinov2_layers import SwiGLUFFNFused
+    torch.manual_seed(0)
+    ffn = SwiGLUFFNFused(128, 256).cuda()
+    x = torch.randn(2, 50, 128).cuda()
+    with torch.no_grad():
+        got = ffn(x).cpu()
+        x12 = F.linear(x.cpu(), ffn.w12.weight.cpu(), ffn.w12.bias.cpu())
+        a, b = x12.chunk(2, -1)
+        ref = F.linear(F.silu(a) * b, ffn.w3.weight.cpu(), ffn.w3.bias.cpu())
+    assert rel_l1(got, ref) < 3e-3

@@ -3,7 +3,7 @@ by oracle/make_golden.py from /root/reference).  This is what pins the oracle; i
 import pytest
 import torch
 
-from _cases import build_product_model, case_inputs, golden_names, load_golden, oracle_forward, synth_state_dict
+from _cases import case_inputs, golden_names, load_golden, oracle_forward, schema_state_dict
 
 FAST = [n for n in golden_names() if n not in ("vitl_518", "vitb_518", "raw_vitg_224")]
 SLOW = [n for n in golden_names() if n in ("vitl_518", "vitb_518", "raw_vitg_224")]
@@ -13,8 +13,7 @@ SLOW = [n for n in golden_names() if n in ("vitl_518", "vitb_518", "raw_vitg_224
 def test_oracle_matches_reference_golden(name):
     gold, meta = load_golden(name)
     case = meta["case"]
-    model = build_product_model(case)          # only used for the key/shape schema
-    sd = synth_state_dict(model, meta)
+    sd = schema_state_dict(case, meta)         # reference key/shape schema fixture + deterministic fill
     x, grgb, mask, obs = case_inputs(case)
     out = oracle_forward(sd, case, x, grgb, mask, obs)
     assert list(out.shape) == meta["out_shape"]

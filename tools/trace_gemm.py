@@ -31,7 +31,7 @@ for name in sys.argv[1:] or ["proj"]:
     else:
         args.update(out_f32=torch.empty(M, N, device="cuda"), ldo_f32=N)
     nblk = ((M + 255) // 256) * ((N + 255) // 256)
-    buf = torch.zeros(nblk * 6, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
     for _ in range(3):
         H.igemm(**args)
     torch.cuda.synchronize()
@@ -39,7 +39,7 @@ for name in sys.argv[1:] or ["proj"]:
     H.igemm(**args)
     torch.cuda.synchronize()
     lib.ada_debug_set_timestamps(None)
-    d = buf.cpu().reshape(nblk, 6)
+    d = buf.cpu().reshape(nblk, 8)
     t0 = int(d[:, 0].min())
     ent, first, loop, end = [(d[:, i] - t0).double() for i in range(4)]
     xcc = (d[:, 4] >> 32) & 0xF
@@ -50,6 +50,7 @@ for name in sys.argv[1:] or ["proj"]:
     print(f"   prologue (entry->first slab): mean {float((first - ent).mean()):8.0f}  max {float((first - ent).max()):8.0f}")
     print(f"   main loop                  : mean {float((loop - first).mean()):8.0f}  min {float((loop - first).min()):8.0f} max {float((loop - first).max()):8.0f}  per k-step {float((loop - first).mean()) / (K // 64 - 0):.0f}")
     print(f"   epilogue                   : mean {float((end - loop).mean()):8.0f}  min {float((end - loop).min()):8.0f} max {float((end - loop).max()):8.0f}")
+    print(f"   wave0 waits in main loop   : vmcnt mean {float(d[:, 6].double().mean()):8.0f}  barrier mean {float(d[:, 7].double().mean()):8.0f}  (per k-step {float(d[:, 6].double().mean()) / (K // 64):.0f} / {float(d[:, 7].double().mean()) / (K // 64):.0f})")
     order = torch.argsort(ent)
     # round structure: entry time histogram
     e = ent[order]

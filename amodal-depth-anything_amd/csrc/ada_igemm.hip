@@ -209,7 +209,57 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
         slab_offsets(0, aoff, boff);
         stage_part(0, aoff, boff, -1);
     }
-    if (NWAVES == 8 && p.sched == 3) {
+    if (p.sched == 4) {
+        // schedule 4: hand-counted LDS pipeline.  Fragment reads are inline-asm ds_read_b128 (invisible to hipcc's
+        // s_waitcnt pass, which otherwise drains lgkmcnt(0) in front of every MFMA cluster and exposes the LDS latency);
+        // the reads of sub-step s+1 are issued before the wait for sub-step s, which is a COUNTED lgkmcnt(TI+TJ): LDS
+        // returns in order, so the older TI+TJ reads are complete while the newer ones stay in flight behind the MFMAs.
+        const unsigned lds0 = (unsigned)(size_t)smem;
+        unsigned cofs[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) cofs[s2] = ((2 * s2 + hi) ^ swz) * 16;
+        const unsigned a_base = lds0 + a_row_off, b_base = lds0 + b_row_off;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (p.dbg && kt == 0) t_first = __builtin_amdgcn_s_memtime();
+            const bool more = kt + 1 < nk;
+            long aoff = 0, boff = 0;
+            if (more) slab_offsets(kt + 1, aoff, boff);
+            const unsigned sa = a_base + cur * STAGE_BYTES, sb = b_base + cur * STAGE_BYTES;
+            opx8 af[2][TI], bf[2][TJ];
+            auto issue = [&](int buf, int s2) {
+                const unsigned aa = sa + cofs[s2], bb = sb + cofs[s2];
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[buf][i]) : "v"(aa), "i"(i * 4096));
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[buf][j]) : "v"(bb), "i"(j * 4096));
+            };
+            issue(0, 0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s < 3) issue((s + 1) & 1, s + 1);
+                if (more) stage_part(cur ^ 1, aoff, boff, s);
+                if (s < 3) {
+                    if constexpr (TI + TJ == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                    else if constexpr (TI + TJ == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                    else if constexpr (TI + TJ == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(af[s & 1][i], bf[s & 1][j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else if (NWAVES == 8 && p.sched == 3) {
         // schedule 3 ("ping-pong"): the two waves that share a SIMD (wave w and w+4) run half a k-step apart.  Each
         // k-step has two barrier intervals; in one of them a wave only moves data (P1: first fragment reads, and for
         // the late group its global->LDS copies), in the other it issues its 32 MFMAs (P2).  Group 0 (waves 0-3) is in

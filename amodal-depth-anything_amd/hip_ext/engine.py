@@ -8,7 +8,7 @@ engine owns everything derived from them:
   1x1 weights as [N, K]; 3x3 weights as [N, 9*Cp] (tap-major, channels padded to 64); transposed-conv
   weights as [s*s*Cout, Cin] with the bias expanded; the RGB and guidance patch-embed filters fused
   into one [D, 1024] matrix (reference DA2/dinov2.py:237-240 adds the two embeddings, so one GEMM over
-  the concatenated K does both); the q rows of qkv pre-multiplied by head_dim**-0.5 = 2**-3 (exact).
+  the concatenated K does both); the q rows of qkv pre-multiplied by head_dim**-0.5 * log2(e) (base-2 softmax in the attention kernel).
 * ``Workspace`` -- every activation buffer for a (batch, H, W), allocated once and kept resident in HBM.
 
 Data layout: the residual stream is fp32 [B*N, D]; every tensor that is only ever a contraction
@@ -42,6 +42,7 @@ VIT = {
     "vitg": dict(dim=1536, depth=40, heads=24, ffn="swiglu"),
 }
 TAPS = {"vits": [2, 5, 8, 11], "vitb": [2, 5, 8, 11], "vitl": [4, 11, 17, 23], "vitg": [9, 19, 29, 39]}
+Q_PRESCALE = 0.125 * 1.4426950408889634  # head_dim**-0.5 * log2(e), head_dim = 64
 MAX_ROWS = (1 << 24) - 1  # row-index limit of the kernels' fast division
 
 
@@ -101,8 +102,10 @@ class PackedWeights:
         for i in range(self.depth):
             b = f"{p}blocks.{i}."
             qw, qb = f32(b + "attn.qkv.weight").clone(), f32(b + "attn.qkv.bias").clone()
-            qw[:D] *= 0.125  # head_dim ** -0.5 with head_dim = 64 (reference attention.py:41,53): exact in any binary format
-            qb[:D] *= 0.125
+            # q * head_dim**-0.5 (reference attention.py:41,53) folded into the weights, together with log2(e): the attention
+            # kernel runs its softmax in base 2 (exp2 is the native transcendental), softmax_e(s) == softmax_2(s * log2 e)
+            qw[:D] *= Q_PRESCALE
+            qb[:D] *= Q_PRESCALE
             blk = dict(
                 ln1_w=f32(b + "norm1.weight"), ln1_b=f32(b + "norm1.bias"),
                 qkv_w=lin(qw), qkv_b=qb,

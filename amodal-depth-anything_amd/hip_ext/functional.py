@@ -110,12 +110,13 @@ def self_attention(x, qkv_w, qkv_b, proj_w, proj_b, num_heads):
     B, N, C = x.shape
     if C // num_heads != 64:
         raise HipExtError("self_attention: the fused kernel is built for head_dim 64 (every DINOv2 size)")
+    from .engine import Q_PRESCALE
     w = qkv_w.detach().float().clone()
-    w[:C] *= 0.125
+    w[:C] *= Q_PRESCALE
     b = None
     if qkv_b is not None:
         b = qkv_b.detach().float().clone()
-        b[:C] *= 0.125
+        b[:C] *= Q_PRESCALE
     qkv = linear(x, w, b, out_operand=True).reshape(B * N, 3 * C)
     o = torch.empty(B * N, C, dtype=operand_dtype(), device=x.device)
     k_attention(qkv, o, B, N, num_heads)

@@ -127,8 +127,8 @@ int ada_igemm(const ada_igemm_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused scaled-dot-product attention, head_dim 64 (all of ViT-S/B/L/G):
- *   softmax(q k^T) v per (batch, head), q already scaled by head_dim^-0.5 (folded into the qkv
- *   weights by the packer).  Replaces DA2/dinov2_layers/attention.py:53-59 (and the xformers
+ *   softmax(q k^T) v per (batch, head).  q must arrive pre-scaled by head_dim^-0.5 * log2(e) (folded into
+ *   the qkv weights by the packer): the kernel evaluates the softmax in base 2, softmax_e(s) = softmax_2(s log2 e).  Replaces DA2/dinov2_layers/attention.py:53-59 (and the xformers
  *   memory_efficient_attention call at :76).  qkv is the packed output of the qkv linear:
  *   [B*N, 3*heads*64] with column = which*heads*64 + head*64 + d (attention.py:51 reshape).
  *   out: [B*N, heads*64] op-typed (the "transpose(1,2).reshape(B,N,C)" layout of :59).

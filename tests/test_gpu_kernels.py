@@ -8,6 +8,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+LOG2E = 1.4426950408889634
 
 
 def _op(hip):
@@ -193,12 +194,12 @@ def test_attention(hip, B, N, heads):
     op = _op(hip)
     D = heads * 64
     qkv = _rand(B * N, 3 * D, seed=33).to(op)
-    qkv[:, :D] *= 0.125  # the packer folds head_dim**-0.5 into q
+    qkv[:, :D] *= 0.125 * LOG2E  # the packer folds head_dim**-0.5 * log2(e) into q (base-2 softmax in the kernel)
     qkv = qkv.to(op)
     out = torch.zeros(B * N, D, dtype=op, device=DEV)
     hip.attention(qkv.to(DEV), out, B, N, heads)
     t = qkv.float().reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
-    p = (t[0] @ t[1].transpose(-2, -1)).softmax(-1)
+    p = ((t[0] @ t[1].transpose(-2, -1)) / LOG2E).softmax(-1)
     ref = (p @ t[2]).transpose(1, 2).reshape(B * N, D)
     _close(out, ref, 2e-3, rtol=1e-2 if op == torch.bfloat16 else 3e-3, what="attention")
 
@@ -213,7 +214,7 @@ def test_attention_forces_online_rescale(hip):
     out = torch.zeros(N, 64, dtype=op, device=DEV)
     hip.attention(qkv.to(DEV), out, B, N, heads)
     t = qkv.float()
-    p = (t[:, :64] @ t[:, 64:128].T).softmax(-1)
+    p = ((t[:, :64] @ t[:, 64:128].T) / LOG2E).softmax(-1)
     _close(out, p @ t[:, 128:], 2e-3, rtol=1e-2 if op == torch.bfloat16 else 3e-3, what="attention rescale")
 
 

@@ -165,35 +165,38 @@ struct BilinearArgs {
     FastDiv dC4, dWo, dHo;
 };
 
-__global__ __launch_bounds__(256) void bilinear_kernel(BilinearArgs p, long total) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    // gid = ((b*ho + y)*wo + x)*c4 + c ; decompose with 32-bit pieces (pixel count < 2^24 is checked on the host)
-    const uint32_t pix = (uint32_t)(gid / p.c4);
-    const int c = (int)(gid - (long)pix * p.c4);
-    uint32_t by, x, b, y;
-    fast_divmod(pix, p.dWo, by, x);
-    fast_divmod(by, p.dHo, b, y);
+// grid: (ceil(wo*c4 / 256), ho, batch) -- one thread per (x, 4-channel group) of an output row: the row's vertical
+// taps are wave-uniform scalars, consecutive lanes walk the channels of one pixel then the next pixel (coalesced
+// float4 loads from the two source rows, contiguous 8/16-byte stores).
+__global__ __launch_bounds__(256) void bilinear_kernel(BilinearArgs p) {
+    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (uint32_t)(p.wo * p.c4)) return;
+    uint32_t x, c;
+    fast_divmod(idx, p.dC4, x, c);
+    const int y = blockIdx.y, b = blockIdx.z;
     const float fy = p.sy * (float)y, fx = p.sx * (float)x;
     const int y0 = (int)fy, x0 = (int)fx;
     const int y1 = y0 + (y0 < p.hi - 1 ? 1 : 0), x1 = x0 + (x0 < p.wi - 1 ? 1 : 0);
     const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
     const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
     const long rb = (long)b * p.hi;
-    const float4 v00 = ((const float4*)(p.in + ((rb + y0) * p.wi + x0) * p.ld_in))[c];
-    const float4 v01 = ((const float4*)(p.in + ((rb + y0) * p.wi + x1) * p.ld_in))[c];
-    const float4 v10 = ((const float4*)(p.in + ((rb + y1) * p.wi + x0) * p.ld_in))[c];
-    const float4 v11 = ((const float4*)(p.in + ((rb + y1) * p.wi + x1) * p.ld_in))[c];
+    const float* r0 = p.in + (rb + y0) * p.wi * p.ld_in;
+    const float* r1 = p.in + (rb + y1) * p.wi * p.ld_in;
+    const float4 v00 = ((const float4*)(r0 + (long)x0 * p.ld_in))[c];
+    const float4 v01 = ((const float4*)(r0 + (long)x1 * p.ld_in))[c];
+    const float4 v10 = ((const float4*)(r1 + (long)x0 * p.ld_in))[c];
+    const float4 v11 = ((const float4*)(r1 + (long)x1 * p.ld_in))[c];
     float4 r;
     r.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
     r.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
     r.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
     r.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+    const long pix = ((long)b * p.ho + y) * p.wo + x;
     if (p.add) {
-        const float4 a = ((const float4*)(p.add + (long)pix * p.ld_add))[c];
+        const float4 a = ((const float4*)(p.add + pix * p.ld_add))[c];
         r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
     }
-    if (p.out_f32) ((float4*)(p.out_f32 + (long)pix * p.ld_f32))[c] = r;
+    if (p.out_f32) ((float4*)(p.out_f32 + pix * p.ld_f32))[c] = r;
     if (p.out_op) {
         long orow = pix;
         if (p.map_op == ADA_MAP_PAD) orow = ((long)b * (p.ho + 2) + (y + 1)) * (p.wo + 2) + (x + 1);
@@ -276,7 +279,8 @@ extern "C" int ada_bilinear_fwd(const float* in, int64_t ld_in, int32_t batch, i
     p.add = add; p.ld_add = ld_add; p.out_f32 = out_f32; p.ld_f32 = ld_f32; p.out_op = (op_t*)out_op; p.ld_op = ld_op;
     p.map_op = map_op; p.relu = relu;
     p.dC4 = make_fastdiv(p.c4); p.dWo = make_fastdiv(wo); p.dHo = make_fastdiv(ho);
-    const long total = (long)batch * ho * wo * p.c4;
-    hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, total);
+    ADA_REQUIRE(ho <= 65535 && batch <= 65535, ADA_EUNSUPPORTED, "ada_bilinear_fwd: ho / batch exceed the grid limits");
+    hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)((wo * p.c4 + 255) / 256), (unsigned)ho, (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, p);
     return ada_check_launch("ada_bilinear_fwd");
 }

@@ -1,16 +1,20 @@
 // Implicit-GEMM contraction with fused epilogues (see include/ada_hip.h: ada_igemm).
 //
-// Tiling (gfx950).  A workgroup computes a BM x BN output tile with BK = 64; each wave owns TI x TJ MFMA
+// Tiling (gfx950).  A workgroup computes a BM x BN output tile in k-steps of BK; each wave owns TI x TJ MFMA
 // tiles of 32x32 (v_mfma_f32_32x32x16, fp32 accumulate).  Tile shapes:
-//     256 x 256, 8 waves (2 x 4), wave tile 128 x 64   -- the workhorse: 128 FLOP per LDS byte staged, so the
-//                                                        L2 -> LDS stream stays well under the L2 roofline
-//     256 x 128, 8 waves (4 x 2), wave tile  64 x 64   -- N = 128 (output_conv1)
-//     128 x  64 / 256 x 32, 4 waves                    -- narrow outputs (ViT-S projections, the 32-channel tail conv)
-// A and W k-slabs (rows of 64 operands = 128 B) go HBM/L2 -> LDS with 16-byte global_load_lds (no VGPR round
+//     256 x 256 x 64, 8 waves (2 x 4), wave tile 128 x 64  -- 1 workgroup / CU, 128 FLOP per LDS byte staged: best when the
+//                                                            k-loop is long (3x3 convs, fc2)
+//     128 x 256 x 32, 4 waves (2 x 2), wave tile  64 x 128 -- 2-3 independent workgroups / CU (48 KB LDS each): the epilogue
+//                                                            (HBM-latency bound, ~10 B/clk/CU) of one tile overlaps the MFMAs
+//                                                            of another -- short-K transformer GEMMs (qkv, proj, fc1)
+//     256 x 128 x 64, 8 waves (4 x 2)                      -- N = 128 (output_conv1)
+//     128 x  64 / 256 x 32 x 64, 4 waves                   -- narrow outputs (ViT-S projections, the 32-channel tail conv)
+// A and W k-slabs (rows of BK operands = 128 or 64 B) go HBM/L2 -> LDS with 16-byte global_load_lds (no VGPR round
 // trip), two LDS stages, one barrier per k-step; the loads of slab t+1 are in flight during the MFMAs of slab t.
 // LDS rows are stored linearly (global_load_lds writes wave base + lane*16) but each lane *fetches* chunk
-// c ^ ((row>>1)&7) of its row and the fragment reads apply the same XOR, so every ds_read_b128 lane group
-// hits 16 distinct 16-byte bank slots (cdna_hip_programming.md T2 / rule 21).
+// c ^ key(row) of its row (key = (row>>1)&7 for 128-byte rows, (row>>2)&3 for 64-byte rows) and the fragment reads
+// apply the same XOR, so every ds_read_b128 lane group hits 16 distinct 16-byte bank slots (0 conflicts measured;
+// cdna_hip_programming.md T2 / rule 21).
 // For a 3x3 convolution the A slab of k-step (tap, kc) is the same 128-byte row segment shifted by
 // (dy*Wp + dx) pixels in the zero-bordered NHWC input: the im2col gather costs one scalar add per k-step.
 //
@@ -23,7 +27,6 @@
 
 namespace {
 
-constexpr int BK = 64;
 
 enum { EPI_STD = 0, EPI_GELU = 1, EPI_SHUFFLE = 2, EPI_SWIGLU = 3, EPI_TAIL = 4 };
 
@@ -92,20 +95,24 @@ ADA_DEV opx4 pack4(float4 v) {
     return o;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmDev p) {
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int NT = NWAVES * 64;
     constexpr int TI = BM / (WAVES_M * 32);
     constexpr int TJ = BN / (WAVES_N * 32);
-    constexpr int A_BYTES = BM * BK * 2;
-    constexpr int B_BYTES = BN * BK * 2;
+    constexpr int RB = BK * 2;                  // bytes per LDS row
+    constexpr int CHUNKS = RB / 16;             // 16-byte chunks per row (8 or 4)
+    constexpr int NSUB = BK / 16;               // MFMA k-sub-steps per k-step (4 or 2)
+    constexpr int A_BYTES = BM * RB;
+    constexpr int B_BYTES = BN * RB;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int ROWS_PER_PASS = NT / 8;  // 8 lanes (16-byte chunks) per 128-byte row
+    constexpr int ROWS_PER_PASS = NT / CHUNKS;  // rows copied by one workgroup-wide global_load_lds pass
     constexpr int A_IT = BM / ROWS_PER_PASS;
     constexpr int B_IT = BN / ROWS_PER_PASS;
-    static_assert(A_IT >= 1 && B_IT >= 1, "tile smaller than one staging pass");
-    static_assert(TJ == 1 || TJ == 2, "wave tile is 32 or 64 columns wide");
+    static_assert(BK == 64 || BK == 32, "BK is 64 or 32");
+    static_assert(A_IT >= 1 && B_IT >= 1 && BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile vs staging pass");
+    static_assert(TJ == 1 || TJ == 2 || TJ == 4, "wave tile is 32, 64 or 128 columns wide");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -128,13 +135,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
     const int m0 = tm * BM, n0 = tn * BN;
     unsigned long long t_entry = 0, t_first = 0, t_loop = 0, t_vm = 0, t_bar = 0;
     if (p.dbg) t_entry = __builtin_amdgcn_s_memtime();
-    if (p.skew > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
-        for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(127);
-    }
 
     // ---- per-thread staging addresses --------------------------------------------------
-    const int srow = tid >> 3;                        // row inside a staging pass
-    const int gchunk = (tid & 7) ^ ((tid >> 4) & 7);  // swizzled source chunk: key (row>>1)&7 == (tid>>4)&7
+    const int srow = tid / CHUNKS;                                  // row inside a staging pass
+    const int gchunk = (tid % CHUNKS) ^ ((tid >> 4) & (CHUNKS - 1));  // swizzled source chunk; key(row) == (tid>>4)&(CHUNKS-1)
     const op_t* a_ptr[A_IT];
     const op_t* b_ptr[B_IT];
 #pragma unroll
@@ -160,30 +164,31 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
     }
 
     // k-step kt -> element offsets of its A and W slabs (wave-uniform scalars)
+    const int cps = (int)(p.lda / BK);  // k-steps per conv tap
     auto slab_offsets = [&](int kt, long& aoff, long& boff) {
         if (p.a_mode == ADA_A_PLAIN) {
             aoff = (long)kt * BK;
         } else {
-            const int tap = kt / p.cps;
-            const int kc = kt - tap * p.cps;
+            const int tap = kt / cps;
+            const int kc = kt - tap * cps;
             const int dy = tap / 3, dx = tap - dy * 3;
             aoff = ((long)dy * p.Wp + dx) * p.lda + (long)kc * BK;
         }
         boff = (long)kt * BK;
     };
-    // issue the global->LDS copies of one quarter (part 0..3) of a stage; part < 0 issues everything
+    // issue the global->LDS copies of part `part` (of NSUB) of a stage; part < 0 issues everything
     auto stage_part = [&](int buf, long aoff, long boff, int part) {
         char* sa = smem + buf * STAGE_BYTES + wave * 1024;
         char* sb = sa + A_BYTES;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            if (part < 0 || (it & 3) == part)
+            if (part < 0 || (it % NSUB) == part)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[it] + aoff),
                                                  (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            if (part < 0 || ((it + 2) & 3) == part)
+            if (part < 0 || ((it + NSUB / 2) % NSUB) == part)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[it] + boff),
                                                  (__attribute__((address_space(3))) void*)(sb + it * (NT * 16)), 16, 0, 0);
         }
@@ -199,9 +204,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int swz = (l31 >> 1) & 7;
-    const int a_row_off = (wm * TI * 32 + l31) * 128;
-    const int b_row_off = A_BYTES + (wn * TJ * 32 + l31) * 128;
+    const int swz = (CHUNKS == 8) ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
+    const int a_row_off = (wm * TI * 32 + l31) * RB;
+    const int b_row_off = A_BYTES + (wn * TJ * 32 + l31) * RB;
 
     const int nk = p.K / BK;
     {
@@ -215,9 +220,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
         // the reads of sub-step s+1 are issued before the wait for sub-step s, which is a COUNTED lgkmcnt(TI+TJ): LDS
         // returns in order, so the older TI+TJ reads are complete while the newer ones stay in flight behind the MFMAs.
         const unsigned lds0 = (unsigned)(size_t)smem;
-        unsigned cofs[4];
+        unsigned cofs[NSUB];
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) cofs[s2] = ((2 * s2 + hi) ^ swz) * 16;
+        for (int s2 = 0; s2 < NSUB; ++s2) cofs[s2] = ((2 * s2 + hi) ^ swz) * 16;
         const unsigned a_base = lds0 + a_row_off, b_base = lds0 + b_row_off;
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
@@ -233,17 +238,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
                 const unsigned aa = sa + cofs[s2], bb = sb + cofs[s2];
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[buf][i]) : "v"(aa), "i"(i * 4096));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[buf][i]) : "v"(aa), "i"(i * 32 * RB));
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[buf][j]) : "v"(bb), "i"(j * 4096));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[buf][j]) : "v"(bb), "i"(j * 32 * RB));
             };
             issue(0, 0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (s < 3) issue((s + 1) & 1, s + 1);
+            for (int s = 0; s < NSUB; ++s) {
+                if (s + 1 < NSUB) issue((s + 1) & 1, s + 1);
                 if (more) stage_part(cur ^ 1, aoff, boff, s);
-                if (s < 3) {
+                if (s + 1 < NSUB) {
                     if constexpr (TI + TJ == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
                     else if constexpr (TI + TJ == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
                     else if constexpr (TI + TJ == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
@@ -259,72 +264,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-    } else if (NWAVES == 8 && p.sched == 3) {
-        // schedule 3 ("ping-pong"): the two waves that share a SIMD (wave w and w+4) run half a k-step apart.  Each
-        // k-step has two barrier intervals; in one of them a wave only moves data (P1: first fragment reads, and for
-        // the late group its global->LDS copies), in the other it issues its 32 MFMAs (P2).  Group 0 (waves 0-3) is in
-        // P2 while group 1 (waves 4-7) is in P1 and vice versa, so the matrix pipe always has one wave feeding it.
-        //   physical barrier #:   1        2        3        4
-        //   group 0:        P1(0) | P2(0) | P1(1) | P2(1) | ...
-        //   group 1:        (x)   | P1(0) | P2(0) | P1(1) | ...
-        // LDS hazards: slab t+1 is copied into the buffer of slab t-1.  Group 0 issues its copies inside P2(t) (group 1
-        // finished P2(t-1) at the barrier before), group 1 at the start of its P1(t) (same interval); both wait for
-        // their own copies (vmcnt(0)) before the barrier that ends that interval, after which group 0 starts P1(t+1).
-        const int grp = wave >> 2;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (p.dbg) t_first = __builtin_amdgcn_s_memtime();
-        if (grp == 1) __builtin_amdgcn_s_barrier();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            const bool more = kt + 1 < nk;
-            long aoff = 0, boff = 0;
-            if (more) slab_offsets(kt + 1, aoff, boff);
-            const char* sbase = smem + cur * STAGE_BYTES;
-            // ---- P1: data movement only
-            if (grp == 1 && more) stage_part(cur ^ 1, aoff, boff, -1);
-            opx8 af[2][TI], bf[2][TJ];
-            {
-                const int coff = (hi ^ swz) * 16;
-#pragma unroll
-                for (int i = 0; i < TI; ++i) af[0][i] = *(const opx8*)(sbase + a_row_off + i * 32 * 128 + coff);
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) bf[0][j] = *(const opx8*)(sbase + b_row_off + j * 32 * 128 + coff);
-            }
-            if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- P2: MFMAs (group 0 also issues its copies of slab t+1 in the first two sub-steps)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (grp == 0 && more && s < 2) {
-                    stage_part(cur ^ 1, aoff, boff, 2 * s);
-                    stage_part(cur ^ 1, aoff, boff, 2 * s + 1);
-                }
-                if (s < 3) {
-                    const int coff = ((2 * (s + 1) + hi) ^ swz) * 16;
-#pragma unroll
-                    for (int i = 0; i < TI; ++i) af[(s + 1) & 1][i] = *(const opx8*)(sbase + a_row_off + i * 32 * 128 + coff);
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j) bf[(s + 1) & 1][j] = *(const opx8*)(sbase + b_row_off + j * 32 * 128 + coff);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(af[s & 1][i], bf[s & 1][j], acc[i][j]);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (grp == 0) __builtin_amdgcn_s_barrier();
-    } else if (p.sched == 0) {
+    } else {
         // schedule 0: all copies of slab t+1 issued right after the barrier, compiler-scheduled fragment reads
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
@@ -346,111 +286,83 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
             }
             const char* sbase = smem + cur * STAGE_BYTES;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < NSUB; ++s) {
                 const int coff = ((2 * s + hi) ^ swz) * 16;
                 opx8 af[TI], bf[TJ];
 #pragma unroll
-                for (int i = 0; i < TI; ++i) af[i] = *(const opx8*)(sbase + a_row_off + i * 32 * 128 + coff);
+                for (int i = 0; i < TI; ++i) af[i] = *(const opx8*)(sbase + a_row_off + i * 32 * RB + coff);
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) bf[j] = *(const opx8*)(sbase + b_row_off + j * 32 * 128 + coff);
+                for (int j = 0; j < TJ; ++j) bf[j] = *(const opx8*)(sbase + b_row_off + j * 32 * RB + coff);
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
             }
         }
-    } else {
-        // schedule 1/2: fragments of sub-step s+1 are read while the MFMAs of sub-step s run (register double
-        // buffer), and the global->LDS copies of slab t+1 are spread over the four sub-steps instead of bunched
-        // behind the barrier; schedule 2 additionally raises the wave priority around each MFMA cluster.
-        const bool prio = p.sched >= 2;
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const bool more = kt + 1 < nk;
-            long aoff = 0, boff = 0;
-            if (more) slab_offsets(kt + 1, aoff, boff);
-            const char* sbase = smem + cur * STAGE_BYTES;
-            opx8 af[2][TI], bf[2][TJ];
-            {
-                const int coff = (hi ^ swz) * 16;
-#pragma unroll
-                for (int i = 0; i < TI; ++i) af[0][i] = *(const opx8*)(sbase + a_row_off + i * 32 * 128 + coff);
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) bf[0][j] = *(const opx8*)(sbase + b_row_off + j * 32 * 128 + coff);
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (more) stage_part(cur ^ 1, aoff, boff, s);
-                if (s < 3) {
-                    const int coff = ((2 * (s + 1) + hi) ^ swz) * 16;
-#pragma unroll
-                    for (int i = 0; i < TI; ++i) af[(s + 1) & 1][i] = *(const opx8*)(sbase + a_row_off + i * 32 * 128 + coff);
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j) bf[(s + 1) & 1][j] = *(const opx8*)(sbase + b_row_off + j * 32 * 128 + coff);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (prio) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(af[s & 1][i], bf[s & 1][j], acc[i][j]);
-                if (prio) __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
     }
 
     // ---- epilogue: transpose through a wave-private LDS slab, then float4 per lane ----------------
-    __syncthreads();
-    if (p.dbg) t_loop = __builtin_amdgcn_s_memtime();  // every wave is done reading the last stage before the slabs overwrite it
-    constexpr int WCOLS = TJ * 32;                    // columns of this wave's tile
-    float* slab = (float*)(smem + wave * (32 * WCOLS * 4));
+    // The wave tile is walked in 32-row x GW-column groups (GW = 64, or 32 for the narrow tiles).
+    __syncthreads();  // every wave is done reading the last stage before the slabs overwrite it
+    if (p.dbg) t_loop = __builtin_amdgcn_s_memtime();
+    constexpr int GW = TJ >= 2 ? 64 : 32;      // columns per epilogue group
+    constexpr int GJ = GW / 32;                // MFMA tiles per group
+    constexpr int NG = TJ / GJ;                // groups per wave-tile row block
+    static_assert(NWAVES * 32 * GW * 4 <= 2 * STAGE_BYTES, "epilogue slabs must fit in the stage buffers");
+    float* slab = (float*)(smem + wave * (32 * GW * 4));
     const int flags = p.flags;
-    const int nbase = n0 + wn * WCOLS;
     const int mbase = m0 + wm * TI * 32;
+    const int nwave = n0 + wn * TJ * 32;
+
+    auto dump = [&](int i, int g) {
+#pragma unroll
+        for (int jj = 0; jj < GJ; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[crow32(r, hi) * GW + jj * 32 + l31] = acc[i][g * GJ + jj][r];
+    };
 
     if constexpr (EPI == EPI_SWIGLU) {
-        // packer interleaved the w12 rows in 32-wide groups: columns [0,32) of the wave tile = x1, [32,64) = x2
-        static_assert(TJ == 2 || EPI != EPI_SWIGLU, "SwiGLU needs a 64-column wave tile");
+        // packer interleaved the w12 rows in 32-wide groups: columns [0,32) of a 64-column group = x1, [32,64) = x2
+        static_assert(GW == 64 || EPI != EPI_SWIGLU, "SwiGLU needs 64-column groups");
         const int c8 = lane & 7, rsub = lane >> 3;
-        const int n1 = nbase + 4 * c8;
-        const bool nval = n1 + 32 < p.N;
-        float4 b1 = make_float4(0, 0, 0, 0), b2 = b1;
-        if (nval && (flags & ADA_EP_BIAS)) {
-            b1 = *(const float4*)(p.bias + n1);
-            b2 = *(const float4*)(p.bias + n1 + 32);
-        }
-        const int nh = (nbase >> 1) + 4 * c8;  // hidden column
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
+        for (int g = 0; g < NG; ++g) {
+            const int nbase = nwave + g * GW;
+            const int n1 = nbase + 4 * c8;
+            const bool nval = n1 + 32 < p.N;
+            float4 b1 = make_float4(0, 0, 0, 0), b2 = b1;
+            if (nval && (flags & ADA_EP_BIAS)) {
+                b1 = *(const float4*)(p.bias + n1);
+                b2 = *(const float4*)(p.bias + n1 + 32);
+            }
+            const int nh = (nbase >> 1) + 4 * c8;  // hidden column
 #pragma unroll
-            for (int j = 0; j < TJ; ++j)
+            for (int i = 0; i < TI; ++i) {
+                dump(i, g);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) slab[crow32(r, hi) * WCOLS + j * 32 + l31] = acc[i][j][r];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int row = k * 8 + rsub;
-                const int m = mbase + i * 32 + row;
-                const float4 x1 = *(const float4*)(slab + row * WCOLS + 4 * c8);
-                const float4 x2 = *(const float4*)(slab + row * WCOLS + 32 + 4 * c8);
-                if (m < p.M && nval) {
-                    float4 g;
-                    float t;
-                    t = x1.x + b1.x; g.x = t / (1.0f + __expf(-t)) * (x2.x + b2.x);
-                    t = x1.y + b1.y; g.y = t / (1.0f + __expf(-t)) * (x2.y + b2.y);
-                    t = x1.z + b1.z; g.z = t / (1.0f + __expf(-t)) * (x2.z + b2.z);
-                    t = x1.w + b1.w; g.w = t / (1.0f + __expf(-t)) * (x2.w + b2.w);
-                    *(opx4*)(p.out_op + (long)m * p.ldo_op + nh) = pack4(g);
+                for (int k = 0; k < 4; ++k) {
+                    const int row = k * 8 + rsub;
+                    const int m = mbase + i * 32 + row;
+                    const float4 x1 = *(const float4*)(slab + row * GW + 4 * c8);
+                    const float4 x2 = *(const float4*)(slab + row * GW + 32 + 4 * c8);
+                    if (m < p.M && nval) {
+                        float4 gt;
+                        float t;
+                        t = x1.x + b1.x; gt.x = t / (1.0f + __expf(-t)) * (x2.x + b2.x);
+                        t = x1.y + b1.y; gt.y = t / (1.0f + __expf(-t)) * (x2.y + b2.y);
+                        t = x1.z + b1.z; gt.z = t / (1.0f + __expf(-t)) * (x2.z + b2.z);
+                        t = x1.w + b1.w; gt.w = t / (1.0f + __expf(-t)) * (x2.w + b2.w);
+                        *(opx4*)(p.out_op + (long)m * p.ldo_op + nh) = pack4(gt);
+                    }
                 }
             }
         }
     } else if constexpr (EPI == EPI_TAIL) {
-        constexpr int CG = WCOLS / 4;
+        constexpr int CG = GW / 4;
         constexpr int RPI = 64 / CG;
+        static_assert(NG == 1 || EPI != EPI_TAIL, "tail epilogue: one column group per wave");
         const int cg = lane % CG, rsub = lane / CG;
-        const int n = nbase + 4 * cg;
+        const int n = nwave + 4 * cg;
         const bool nval = n < p.N;
         float4 bias4 = make_float4(0, 0, 0, 0), tail4 = make_float4(0, 0, 0, 0);
         if (nval) {
@@ -459,15 +371,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
         }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
-#pragma unroll
-            for (int j = 0; j < TJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) slab[crow32(r, hi) * WCOLS + j * 32 + l31] = acc[i][j][r];
+            dump(i, 0);
 #pragma unroll
             for (int k = 0; k < 32 / RPI; ++k) {
                 const int row = k * RPI + rsub;
                 const int m = mbase + i * 32 + row;
-                const float4 v = *(const float4*)(slab + row * WCOLS + 4 * cg);
+                const float4 v = *(const float4*)(slab + row * GW + 4 * cg);
                 float part = __builtin_fmaxf(v.x + bias4.x, 0.f) * tail4.x + __builtin_fmaxf(v.y + bias4.y, 0.f) * tail4.y +
                              __builtin_fmaxf(v.z + bias4.z, 0.f) * tail4.z + __builtin_fmaxf(v.w + bias4.w, 0.f) * tail4.w;
 #pragma unroll
@@ -482,74 +391,74 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
         }
     } else if (!p.out_f32 && !(flags & ADA_EP_RESIDUAL) && (p.ldo_op & 7) == 0 && (EPI != EPI_SHUFFLE || (p.shuffle_c & 7) == 0)) {
         // ---- operand-only output: 8 columns per lane -> one 16-byte store per row segment ----------------
-        constexpr int CG = WCOLS / 8;    // 8-column groups per row (4 or 8)
+        constexpr int CG = GW / 8;       // 8-column groups per row (4 or 8)
         constexpr int RPI = 64 / CG;     // rows per wave-wide access (16 or 8)
         const int cg = lane % CG, rsub = lane / CG;
-        const int n = nbase + 8 * cg;
-        const bool nval = n < p.N;       // N % 8 == 0 on this path (checked below via nval of the second half)
-        const bool nval2 = n + 4 < p.N;
-        float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, g0 = make_float4(1, 1, 1, 1), g1 = g0;
-        if (flags & ADA_EP_BIAS) {
-            if (nval) b0 = *(const float4*)(p.bias + n);
-            if (nval2) b1 = *(const float4*)(p.bias + n + 4);
-        }
-        if (flags & ADA_EP_GAMMA) {
-            if (nval) g0 = *(const float4*)(p.gamma + n);
-            if (nval2) g1 = *(const float4*)(p.gamma + n + 4);
-        }
-        uint32_t sh_i = 0, sh_j = 0, sh_co = 0;
-        if constexpr (EPI == EPI_SHUFFLE) {
-            uint32_t ij;
-            fast_divmod((uint32_t)(nval ? n : 0), p.dShC, ij, sh_co);
-            fast_divmod(ij, p.dShS, sh_i, sh_j);
-        }
         const bool relu = (flags & ADA_EP_RELU_OP) != 0;
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
+        for (int g = 0; g < NG; ++g) {
+            const int n = nwave + g * GW + 8 * cg;
+            const bool nval = n < p.N;
+            const bool nval2 = n + 4 < p.N;
+            float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, g0 = make_float4(1, 1, 1, 1), g1 = g0;
+            if (flags & ADA_EP_BIAS) {
+                if (nval) b0 = *(const float4*)(p.bias + n);
+                if (nval2) b1 = *(const float4*)(p.bias + n + 4);
+            }
+            if (flags & ADA_EP_GAMMA) {
+                if (nval) g0 = *(const float4*)(p.gamma + n);
+                if (nval2) g1 = *(const float4*)(p.gamma + n + 4);
+            }
+            uint32_t sh_i = 0, sh_j = 0, sh_co = 0;
+            if constexpr (EPI == EPI_SHUFFLE) {
+                uint32_t ij;
+                fast_divmod((uint32_t)(nval ? n : 0), p.dShC, ij, sh_co);
+                fast_divmod(ij, p.dShS, sh_i, sh_j);
+            }
 #pragma unroll
-            for (int j = 0; j < TJ; ++j)
+            for (int i = 0; i < TI; ++i) {
+                dump(i, g);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) slab[crow32(r, hi) * WCOLS + j * 32 + l31] = acc[i][j][r];
-#pragma unroll
-            for (int k = 0; k < 32 / RPI; ++k) {
-                const int row = k * RPI + rsub;
-                const int m = mbase + i * 32 + row;
-                float4 v0 = *(const float4*)(slab + row * WCOLS + 8 * cg);
-                float4 v1 = *(const float4*)(slab + row * WCOLS + 8 * cg + 4);
-                v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
-                v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
-                if constexpr (EPI == EPI_GELU) {
-                    v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
-                    v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
-                }
-                v0.x *= g0.x; v0.y *= g0.y; v0.z *= g0.z; v0.w *= g0.w;
-                v1.x *= g1.x; v1.y *= g1.y; v1.z *= g1.z; v1.w *= g1.w;
-                if (relu) {
-                    v0.x = __builtin_fmaxf(v0.x, 0.f); v0.y = __builtin_fmaxf(v0.y, 0.f); v0.z = __builtin_fmaxf(v0.z, 0.f); v0.w = __builtin_fmaxf(v0.w, 0.f);
-                    v1.x = __builtin_fmaxf(v1.x, 0.f); v1.y = __builtin_fmaxf(v1.y, 0.f); v1.z = __builtin_fmaxf(v1.z, 0.f); v1.w = __builtin_fmaxf(v1.w, 0.f);
-                }
-                if (m < p.M && nval) {
-                    long orow;
-                    int ocol = n;
-                    if constexpr (EPI == EPI_SHUFFLE) {
-                        uint32_t sb, rem, sy, sx;
-                        fast_divmod((uint32_t)m, p.dMapHW, sb, rem);
-                        fast_divmod(rem, p.dMapW, sy, sx);
-                        orow = ((long)sb * (p.shuffle_s * p.map_h + 2) + (p.shuffle_s * sy + sh_i + 1)) * (p.shuffle_s * p.map_w + 2) +
-                               (p.shuffle_s * sx + sh_j + 1);
-                        ocol = (int)sh_co;
-                    } else {
-                        orow = map_row(p, p.map_op, (uint32_t)m);
+                for (int k = 0; k < 32 / RPI; ++k) {
+                    const int row = k * RPI + rsub;
+                    const int m = mbase + i * 32 + row;
+                    float4 v0 = *(const float4*)(slab + row * GW + 8 * cg);
+                    float4 v1 = *(const float4*)(slab + row * GW + 8 * cg + 4);
+                    v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
+                    v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
+                    if constexpr (EPI == EPI_GELU) {
+                        v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
+                        v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
                     }
-                    op_t* dst = p.out_op + orow * p.ldo_op + ocol;
-                    if (nval2) {
-                        const opx4 lo = pack4(v0), hi4 = pack4(v1);
-                        opx8 o;
-                        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-                        o[4] = hi4[0]; o[5] = hi4[1]; o[6] = hi4[2]; o[7] = hi4[3];
-                        *(opx8*)dst = o;
-                    } else {
-                        *(opx4*)dst = pack4(v0);
+                    v0.x *= g0.x; v0.y *= g0.y; v0.z *= g0.z; v0.w *= g0.w;
+                    v1.x *= g1.x; v1.y *= g1.y; v1.z *= g1.z; v1.w *= g1.w;
+                    if (relu) {
+                        v0.x = __builtin_fmaxf(v0.x, 0.f); v0.y = __builtin_fmaxf(v0.y, 0.f); v0.z = __builtin_fmaxf(v0.z, 0.f); v0.w = __builtin_fmaxf(v0.w, 0.f);
+                        v1.x = __builtin_fmaxf(v1.x, 0.f); v1.y = __builtin_fmaxf(v1.y, 0.f); v1.z = __builtin_fmaxf(v1.z, 0.f); v1.w = __builtin_fmaxf(v1.w, 0.f);
+                    }
+                    if (m < p.M && nval) {
+                        long orow;
+                        int ocol = n;
+                        if constexpr (EPI == EPI_SHUFFLE) {
+                            uint32_t sb, rem, sy, sx;
+                            fast_divmod((uint32_t)m, p.dMapHW, sb, rem);
+                            fast_divmod(rem, p.dMapW, sy, sx);
+                            orow = ((long)sb * (p.shuffle_s * p.map_h + 2) + (p.shuffle_s * sy + sh_i + 1)) * (p.shuffle_s * p.map_w + 2) +
+                                   (p.shuffle_s * sx + sh_j + 1);
+                            ocol = (int)sh_co;
+                        } else {
+                            orow = map_row(p, p.map_op, (uint32_t)m);
+                        }
+                        op_t* dst = p.out_op + orow * p.ldo_op + ocol;
+                        if (nval2) {
+                            const opx4 lo = pack4(v0), hi4 = pack4(v1);
+                            opx8 o;
+                            o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+                            o[4] = hi4[0]; o[5] = hi4[1]; o[6] = hi4[2]; o[7] = hi4[3];
+                            *(opx8*)dst = o;
+                        } else {
+                            *(opx4*)dst = pack4(v0);
+                        }
                     }
                 }
             }
@@ -557,26 +466,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
     } else {
         // ---- fp32 output and/or residual: 4 columns per lane; the residual loads of a whole 32-row pass are issued
         //      together (clamped, unconditional) one pass ahead, so their HBM latency hides behind the LDS transpose ----
-        constexpr int CG = WCOLS / 4;    // float4 column groups per row (8 or 16)
+        constexpr int CG = GW / 4;       // float4 column groups per row (8 or 16)
         constexpr int RPI = 64 / CG;     // rows covered by one wave-wide float4 read (8 or 4)
         constexpr int NKI = 32 / RPI;
+        constexpr int NPASS = NG * TI;   // pass index q = g * TI + i
         const int cg = lane % CG, rsub = lane / CG;
-        const int n = nbase + 4 * cg;
-        const bool nval = n < p.N;       // N % 4 == 0 is checked on the host
-        const int nc = nval ? n : 0;
-        float4 bias4 = make_float4(0, 0, 0, 0), gamma4 = make_float4(1, 1, 1, 1);
-        if (flags & ADA_EP_BIAS) bias4 = *(const float4*)(p.bias + nc);
-        if (flags & ADA_EP_GAMMA) gamma4 = *(const float4*)(p.gamma + nc);
-        uint32_t sh_i = 0, sh_j = 0, sh_co = 0;
-        if constexpr (EPI == EPI_SHUFFLE) {
-            uint32_t ij;
-            fast_divmod((uint32_t)nc, p.dShC, ij, sh_co);
-            fast_divmod(ij, p.dShS, sh_i, sh_j);
-        }
         const bool has_res = (flags & ADA_EP_RESIDUAL) != 0;
-        auto res_ptr = [&](int i, int k) -> const float* {
+        auto col_of = [&](int g) { return nwave + g * GW + 4 * cg; };
+        auto res_ptr = [&](int q, int k) -> const float* {
+            const int g = q / TI, i = q - g * TI;
             int m = mbase + i * 32 + k * RPI + rsub;
             if (m >= p.M) m = p.M - 1;
+            int nc = col_of(g);
+            if (nc >= p.N) nc = 0;
             long rrow;
             if (p.res_row_mod > 0) {
                 uint32_t qq, rr;
@@ -587,28 +489,48 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
             }
             return p.res + rrow * p.ldr + nc;
         };
-        float4 rcur[NKI], rnext[NKI];
+        // one-pass-ahead prefetch only where a single workgroup owns the CU; with 2-3 co-resident workgroups the other
+        // workgroups' MFMAs already cover the latency and the 32 extra VGPRs would spill
+        constexpr bool AHEAD = NWAVES == 8;
+        float4 rcur[NKI], rnext[AHEAD ? NKI : 1];
 #pragma unroll
-        for (int k = 0; k < NKI; ++k) rcur[k] = rnext[k] = make_float4(0, 0, 0, 0);
-        if (has_res) {
+        for (int k = 0; k < NKI; ++k) rcur[k] = make_float4(0, 0, 0, 0);
+        if (AHEAD && has_res) {
 #pragma unroll
             for (int k = 0; k < NKI; ++k) rcur[k] = *(const float4*)res_ptr(0, k);
         }
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            if (has_res && i + 1 < TI) {
-#pragma unroll
-                for (int k = 0; k < NKI; ++k) rnext[k] = *(const float4*)res_ptr(i + 1, k);
+        for (int q = 0; q < NPASS; ++q) {
+            const int g = q / TI, i = q - g * TI;
+            const int n = col_of(g);
+            const bool nval = n < p.N;       // N % 4 == 0 is checked on the host
+            const int nc = nval ? n : 0;
+            float4 bias4 = make_float4(0, 0, 0, 0), gamma4 = make_float4(1, 1, 1, 1);
+            if (flags & ADA_EP_BIAS) bias4 = *(const float4*)(p.bias + nc);
+            if (flags & ADA_EP_GAMMA) gamma4 = *(const float4*)(p.gamma + nc);
+            uint32_t sh_i = 0, sh_j = 0, sh_co = 0;
+            if constexpr (EPI == EPI_SHUFFLE) {
+                uint32_t ij;
+                fast_divmod((uint32_t)nc, p.dShC, ij, sh_co);
+                fast_divmod(ij, p.dShS, sh_i, sh_j);
             }
+            if constexpr (AHEAD) {
+                if (has_res && q + 1 < NPASS) {
 #pragma unroll
-            for (int j = 0; j < TJ; ++j)
+                    for (int k = 0; k < NKI; ++k) rnext[k] = *(const float4*)res_ptr(q + 1, k);
+                }
+            } else {
+                if (has_res) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) slab[crow32(r, hi) * WCOLS + j * 32 + l31] = acc[i][j][r];
+                    for (int k = 0; k < NKI; ++k) rcur[k] = *(const float4*)res_ptr(q, k);
+                }
+            }
+            dump(i, g);
 #pragma unroll
             for (int k = 0; k < NKI; ++k) {
                 const int row = k * RPI + rsub;
                 const int m = mbase + i * 32 + row;
-                float4 v = *(const float4*)(slab + row * WCOLS + 4 * cg);
+                float4 v = *(const float4*)(slab + row * GW + 4 * cg);
                 v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                 if constexpr (EPI == EPI_GELU) {
                     v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
@@ -646,9 +568,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
                     }
                 }
             }
-            if (has_res) {
+            if constexpr (AHEAD) {
+                if (has_res) {
 #pragma unroll
-                for (int k = 0; k < NKI; ++k) rcur[k] = rnext[k];
+                    for (int k = 0; k < NKI; ++k) rcur[k] = rnext[k];
+                }
             }
         }
     }
@@ -665,13 +589,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
 int launch_cfg(IgemmDev& d, hipStream_t stream) {
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int SMEM = 2 * (BM + BN) * BK * 2;
     d.tiles_m = (d.M + BM - 1) / BM;
     d.tiles_n = (d.N + BN - 1) / BN;
-    auto kern = igemm_kernel<BM, BN, WAVES_M, WAVES_N, EPI>;
+    auto kern = igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
@@ -684,25 +608,30 @@ int launch_cfg(IgemmDev& d, hipStream_t stream) {
     return ada_check_launch("ada_igemm");
 }
 
+// tile configurations: 0: 256x32, 1: 128x64, 2: 256x128, 3: 256x256 (1 WG/CU), 4: 128x128, 5: 128x256x32 (2-3 WG/CU)
 template <int EPI>
-int launch_epi(IgemmDev& d, hipStream_t s, int force) {
-    // tile choice: widest tile whose column count the problem fills; `force` (ADA_IGEMM_TILE env) is for A/B tests
+int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
     int cfg;
     if (d.N <= 32) cfg = 0;
     else if (d.N <= 64) cfg = 1;
     else if (d.N <= 128) cfg = 2;
-    else cfg = 3;
+    else cfg = (d.K <= 2048) ? short_k_cfg : 3;   // short k-loops: the epilogue is a third of the tile time -> overlap it
     if (d.M < 256 && cfg >= 2) cfg = 4;
     if (force >= 0) cfg = force;
     if constexpr (EPI == EPI_SWIGLU) {
-        return cfg == 4 ? launch_cfg<128, 128, 2, 2, EPI>(d, s) : launch_cfg<256, 256, 2, 4, EPI>(d, s);
+        if (cfg == 4) return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
+        if (cfg == 5) return launch_cfg<128, 256, 32, 2, 2, EPI>(d, s);
+        return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
+    } else if constexpr (EPI == EPI_TAIL) {
+        return cfg == 0 ? launch_cfg<256, 32, 64, 4, 1, EPI>(d, s) : launch_cfg<128, 64, 64, 4, 1, EPI>(d, s);
     } else {
         switch (cfg) {
-            case 0: return launch_cfg<256, 32, 4, 1, EPI>(d, s);
-            case 1: return launch_cfg<128, 64, 4, 1, EPI>(d, s);
-            case 2: return launch_cfg<256, 128, 4, 2, EPI>(d, s);
-            case 4: return launch_cfg<128, 128, 2, 2, EPI>(d, s);
-            default: return launch_cfg<256, 256, 2, 4, EPI>(d, s);
+            case 0: return launch_cfg<256, 32, 64, 4, 1, EPI>(d, s);
+            case 1: return launch_cfg<128, 64, 64, 4, 1, EPI>(d, s);
+            case 2: return launch_cfg<256, 128, 64, 4, 2, EPI>(d, s);
+            case 4: return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
+            case 5: return launch_cfg<128, 256, 32, 2, 2, EPI>(d, s);
+            default: return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
         }
     }
 }
@@ -717,13 +646,13 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     ADA_REQUIRE(a != nullptr, ADA_EINVAL, "ada_igemm: null args");
     ADA_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, ADA_EINVAL, "ada_igemm: M/N/K must be positive (%d,%d,%d)", a->M, a->N, a->K);
     ADA_REQUIRE(a->A && a->W, ADA_EINVAL, "ada_igemm: null operand pointer");
-    ADA_REQUIRE(a->K % BK == 0, ADA_EINVAL, "ada_igemm: K=%d must be a multiple of 64", a->K);
+    ADA_REQUIRE(a->K % 64 == 0, ADA_EINVAL, "ada_igemm: K=%d must be a multiple of 64", a->K);
     ADA_REQUIRE(a->lda % 8 == 0 && a->lda > 0, ADA_EINVAL, "ada_igemm: lda=%ld must be a positive multiple of 8", (long)a->lda);
     ADA_REQUIRE(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->W % 16) == 0, ADA_EINVAL, "ada_igemm: operands must be 16-byte aligned");
     ADA_REQUIRE(a->out_f32 || a->out_op, ADA_EINVAL, "ada_igemm: no output buffer");
     ADA_REQUIRE((long)a->M < (1L << 24), ADA_EUNSUPPORTED, "ada_igemm: M=%d exceeds 2^24 rows", a->M);
     if (a->a_mode == ADA_A_CONV3) {
-        ADA_REQUIRE(a->lda % BK == 0, ADA_EINVAL, "ada_igemm: CONV3 needs lda %% 64 == 0 (got %ld)", (long)a->lda);
+        ADA_REQUIRE(a->lda % 64 == 0, ADA_EINVAL, "ada_igemm: CONV3 needs lda %% 64 == 0 (got %ld)", (long)a->lda);
         ADA_REQUIRE(a->K == 9 * a->lda, ADA_EINVAL, "ada_igemm: CONV3 needs K == 9*lda (K=%d lda=%ld)", a->K, (long)a->lda);
         ADA_REQUIRE(a->Ho > 0 && a->Wo > 0 && (a->stride == 1 || a->stride == 2), ADA_EINVAL, "ada_igemm: bad conv geometry");
         ADA_REQUIRE(a->Hp >= (a->Ho - 1) * a->stride + 3 && a->Wp >= (a->Wo - 1) * a->stride + 3, ADA_EINVAL,
@@ -791,25 +720,26 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.dShC = make_fastdiv(a->shuffle_c > 0 ? a->shuffle_c : 1);
     d.dShS = make_fastdiv(a->shuffle_s > 0 ? a->shuffle_s : 1);
     d.tail_w = a->tail_w; d.tail_b = a->tail_b; d.tail_act = a->tail_act;
-    d.cps = (int)(a->lda / BK);
+    d.cps = 0;
     d.tiles_m = d.tiles_n = 0;
 
-    static int force = -2, sched = 0, skew = 0;
+    // A/B switches for kernel experiments (read once): tile override, main-loop schedule, tile used for short k-loops
+    static int force = -2, sched = 0, short_k_cfg = 3;
     if (force == -2) {
         const char* e = getenv("ADA_IGEMM_TILE");
         force = e ? atoi(e) : -1;
         const char* sc = getenv("ADA_IGEMM_SCHED");
         sched = sc ? atoi(sc) : 0;
-        const char* sk = getenv("ADA_IGEMM_SKEW");
-        skew = sk ? atoi(sk) : 0;
+        const char* sk = getenv("ADA_IGEMM_SHORTK");
+        short_k_cfg = sk ? atoi(sk) : 3;
     }
     d.sched = sched;
-    d.skew = skew;
+    d.skew = 0;
     d.dbg = g_dbg;
     hipStream_t s = (hipStream_t)stream;
-    if (tail) return launch_epi<EPI_TAIL>(d, s, a->N <= 32 ? 0 : 1);
-    if (swiglu) return launch_epi<EPI_SWIGLU>(d, s, force);
-    if (shuffle) return launch_epi<EPI_SHUFFLE>(d, s, force);
-    if (f & ADA_EP_GELU) return launch_epi<EPI_GELU>(d, s, force);
-    return launch_epi<EPI_STD>(d, s, force);
+    if (tail) return launch_epi<EPI_TAIL>(d, s, a->N <= 32 ? 0 : 1, 3);
+    if (swiglu) return launch_epi<EPI_SWIGLU>(d, s, force, short_k_cfg);
+    if (shuffle) return launch_epi<EPI_SHUFFLE>(d, s, force, short_k_cfg);
+    if (f & ADA_EP_GELU) return launch_epi<EPI_GELU>(d, s, force, short_k_cfg);
+    return launch_epi<EPI_STD>(d, s, force, short_k_cfg);
 }

@@ -63,7 +63,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("ADA_BENCH_FORCE_DIST"))  # the env switch exercises the RCCL path on one GPU
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -85,12 +86,12 @@ def main():
     model = model.to(dev)
     B = args.batch
     x, _, mask, obs = make_inputs(B, args.size, args.size, seed=100 + rank, device=dev)
-    gathered = [torch.empty(B, 1, args.size, args.size, device=dev) for _ in range(world)] if world > 1 else None
+    gathered = [torch.empty(B, 1, args.size, args.size, device=dev) for _ in range(world)] if use_dist else None
 
     def step():
         with torch.no_grad():
             out = model(x, guide_rgb=None, guide_mask=mask, observation=obs)
-        if world > 1:
+        if use_dist:
             dist.all_gather(gathered, out)  # per-image outputs to every rank (north_star: RCCL all-gather over xGMI)
         return out
 
@@ -100,18 +101,18 @@ def main():
     if not args.no_kernel_timer:
         timer = hip_ext.KernelTimer()
         hip_ext.set_timer(timer)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     hip_ext.set_timer(None)
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -156,7 +157,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.encoder, args.size, guide_type, loss)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -30,6 +30,8 @@ print(f"SCHED={os.environ.get('ADA_IGEMM_SCHED', '0')} TILE={os.environ.get('ADA
 for name, M, N, K, kw, mode in shapes:
     A = (torch.randn(M, K, device=dev) * 1.0).to(op)
     W = (torch.randn(N, K, device=dev) * K ** -0.5).to(op)
+    if os.environ.get("ZERO"):
+        A.zero_(); W.zero_()
     bias = torch.randn(N, device=dev)
     gamma = torch.rand(N, device=dev)
     args = dict(M=M, N=N, K=K, A=A, lda=K, W=W, bias=bias, **kw)

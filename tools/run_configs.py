@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Runs the other BASELINE.json configurations once on the GPU (finite-output + throughput sanity; parity for these model
+families is covered by tests/test_gpu_model.py at smaller sizes):
+   config 2: AmodalDAv2 ViT-B, bs=8, 518x518      config 5: raw Depth-Anything-V2 ViT-G, bs=8, 1022x1022 (1024 is not a
+   multiple of 14 -- SURVEY.md 0.4)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "amodal-depth-anything_amd")):
+    sys.path.insert(0, p)
+import torch
+from src.models import get_model
+from src.models.amodalsynthdrive.depth_anything_v2_raw.dpt import DepthAnythingV2 as Raw
+from src.util.synth_weights import fill_state_dict_, make_inputs
+
+
+def timeit(fn, n=3):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = fn()
+    torch.cuda.synchronize()
+    return out, (time.perf_counter() - t0) / n
+
+
+def synth(m):
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    fill_state_dict_(sd, 0)
+    m.load_state_dict(sd)
+    return m.cuda().eval()
+
+
+with torch.no_grad():
+    m = synth(get_model("AmodalDAv2", guide_type="mask+observation", loss_stategy="entire_target_object", encoder="vitb", pretrained=False))
+    x, _, mask, obs = make_inputs(8, 518, 518, 0, device="cuda")
+    out, dt = timeit(lambda: m(x, guide_mask=mask, observation=obs))
+    print(f"config 2  ViT-B bs=8 518x518: {8 / dt:.1f} images/s ({dt * 1e3:.1f} ms/step, {8 / dt * 396.26 / 1e3:.0f} TFLOP/s), finite={bool(torch.isfinite(out).all())}, range=({float(out.min()):.3f},{float(out.max()):.3f})")
+    del m, out
+    torch.cuda.empty_cache()
+    r = synth(Raw(encoder="vitg", features=384, out_channels=[1536] * 4))
+    xg = torch.randn(8, 3, 1022, 1022, device="cuda")
+    out, dt = timeit(lambda: r(xg), n=2)
+    print(f"config 5  raw ViT-G bs=8 1022x1022: {8 / dt:.2f} images/s ({dt * 1e3:.1f} ms/step, {8 / dt * 22824.89 / 1e3:.0f} TFLOP/s), finite={bool(torch.isfinite(out).all())}, shape={tuple(out.shape)}, mem={torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")

@@ -688,17 +688,37 @@ int launch_cfg(IgemmDev& d, hipStream_t stream) {
 }
 
 // tile configurations: 0: 256x32, 1: 128x64, 2: 256x128, 3: 256x256 (1 WG/CU), 4: 128x128, 5: 128x256x32 (2-3 WG/CU)
+// Relative time of launching `tiles` workgroups of a BMxBN tile with `occ` workgroups resident per CU and main-loop
+// efficiency `eff` (measured, relative to the 256x256 tile): whole rounds of 256*occ tiles, co-resident tiles share a CU.
+static inline double tile_time(long M, long N, int bm, int bn, int occ, double eff) {
+    const long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    const double t = (double)bm * bn / eff;
+    const long slots = 256L * occ;
+    if (tiles <= slots) return ((tiles + 255) / 256) * t;   // partially filled single round
+    return (double)((tiles + slots - 1) / slots) * occ * t;
+}
+
 template <int EPI>
 int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
     int cfg;
     if (d.N <= 32) cfg = 0;
     else if (d.N <= 64) cfg = 1;
     else if (d.N <= 128) cfg = 2;
-    else cfg = (d.K <= 2048) ? short_k_cfg : 3;   // short k-loops: the epilogue is a third of the tile time -> overlap it
-    if (d.M < 256 && cfg >= 2) cfg = 4;
+    else {
+        // large problems: the 256x256 tile (best MFMA efficiency); small ones (single images, ViT-S/B at small batch)
+        // would leave most CUs idle with it, so pick the tile that minimises the quantised time estimate
+        cfg = (d.K <= 2048) ? short_k_cfg : 3;
+        double best = tile_time(d.M, d.N, 256, 256, 1, 1.0);
+        const double t2 = tile_time(d.M, d.N, 256, 128, 1, 0.90), t4 = tile_time(d.M, d.N, 128, 128, 2, 0.85),
+                     t1 = tile_time(d.M, d.N, 128, 64, 3, 0.65);
+        if (t2 < 0.95 * best) { best = t2; cfg = 2; }
+        if (t4 < 0.95 * best) { best = t4; cfg = 4; }
+        if (EPI != EPI_SWIGLU && t1 < 0.95 * best) { best = t1; cfg = 1; }
+    }
+    if (d.M < 256 && cfg >= 2 && cfg != 4) cfg = 4;
     if (force >= 0) cfg = force;
     if constexpr (EPI == EPI_SWIGLU) {
-        if (cfg == 4) return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
+        if (cfg == 4 || cfg == 2) return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
         if (cfg == 5) return launch_cfg<128, 256, 32, 2, 2, EPI>(d, s);
         return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
     } else if constexpr (EPI == EPI_TAIL) {

@@ -738,6 +738,11 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
 }  // namespace
 
 static unsigned long long* g_dbg = nullptr;
+static int g_force_tile = -1, g_sched = 0, g_short_k_cfg = 3;
+static bool g_env_read = false;
+// debug hooks (not part of the stable ABI): override the tile configuration (-1 = heuristic) / main-loop schedule
+extern "C" void ada_debug_set_tile(int cfg) { g_force_tile = cfg; g_env_read = true; }
+extern "C" void ada_debug_set_sched(int sched) { g_sched = sched; }
 // debug hook (not part of the stable ABI): device buffer of 8 x u64 per workgroup, or NULL to disable
 extern "C" void ada_debug_set_timestamps(void* dev_buf) { g_dbg = (unsigned long long*)dev_buf; }
 
@@ -823,16 +828,17 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.tiles_m = d.tiles_n = 0;
 
     // A/B switches for kernel experiments (read once): tile override, main-loop schedule, tile used for short k-loops
-    static int force = -2, sched = 0, short_k_cfg = 3;
-    if (force == -2) {
+    if (!g_env_read) {
+        g_env_read = true;
         const char* e = getenv("ADA_IGEMM_TILE");
-        force = e ? atoi(e) : -1;
+        g_force_tile = e ? atoi(e) : -1;
         const char* sc = getenv("ADA_IGEMM_SCHED");
-        sched = sc ? atoi(sc) : 0;
+        g_sched = sc ? atoi(sc) : 0;
         const char* sk = getenv("ADA_IGEMM_SHORTK");
-        short_k_cfg = sk ? atoi(sk) : 3;
+        g_short_k_cfg = sk ? atoi(sk) : 3;
     }
-    d.sched = sched;
+    const int force = g_force_tile, short_k_cfg = g_short_k_cfg;
+    d.sched = g_sched;
     d.skew = 0;
     d.dbg = g_dbg;
     hipStream_t s = (hipStream_t)stream;

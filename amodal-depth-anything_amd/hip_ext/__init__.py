@@ -28,6 +28,7 @@ ACT_NONE, ACT_SIGMOID, ACT_RELU = 0, 1, 2
 EXPORTS = (
     "ada_abi_version", "ada_operand_dtype", "ada_last_error", "ada_igemm", "ada_attention_fwd",
     "ada_layernorm_fwd", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
+    "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd",
 )
 
 
@@ -95,6 +96,12 @@ def load(path: Optional[str] = None):
     lib.ada_bilinear_fwd.restype = c_int
     lib.ada_selftest.argtypes = [c_void_p, c_int64, c_void_p]
     lib.ada_selftest.restype = c_int
+    lib.ada_minmax_fwd.argtypes = [c_void_p, c_int32, c_int64, c_void_p, c_void_p]
+    lib.ada_minmax_fwd.restype = c_int
+    lib.ada_normalize_fwd.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]
+    lib.ada_normalize_fwd.restype = c_int
+    lib.ada_blend_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
+    lib.ada_blend_fwd.restype = c_int
     if lib.ada_abi_version() != ABI_VERSION:
         raise HipExtError(f"{path}: ABI version {lib.ada_abi_version()} != binding version {ABI_VERSION}")
     _lib, _lib_path = lib, path
@@ -231,6 +238,25 @@ def bilinear(inp, ld_in, batch, hi, wi, ho, wo, channels, *, add=None, ld_add=0,
     _check(load().ada_bilinear_fwd(_dev(inp, "in", torch.float32), ld_in, batch, hi, wi, ho, wo, channels,
                                    _opt(add, "add", torch.float32), ld_add, _opt(out_f32, "out_f32", torch.float32), ld_f32,
                                    _opt(out_op, "out_op", op), ld_op, map_op, int(relu), _stream()), "ada_bilinear_fwd")
+
+
+def minmax(inp, minmax_out):
+    """inp: fp32 [B, ...] contiguous -> minmax_out fp32 [B, 2]."""
+    B = inp.shape[0]
+    _check(load().ada_minmax_fwd(_dev(inp, "in", torch.float32), B, inp.numel() // B, _dev(minmax_out, "minmax", torch.float32), _stream()),
+           "ada_minmax_fwd")
+
+
+def normalize(inp, minmax_in, norm=None, obs=None):
+    B = inp.shape[0]
+    _check(load().ada_normalize_fwd(_dev(inp, "in", torch.float32), _dev(minmax_in, "minmax", torch.float32), B, inp.numel() // B,
+                                    _opt(norm, "norm", torch.float32), _opt(obs, "obs", torch.float32), _stream()), "ada_normalize_fwd")
+
+
+def blend(amodal, base, mask, out):
+    B, H, W = amodal.shape[0], amodal.shape[-2], amodal.shape[-1]
+    _check(load().ada_blend_fwd(_dev(amodal, "amodal", torch.float32), _dev(base, "base", torch.float32), _dev(mask, "mask", torch.float32),
+                                B, H, W, _dev(out, "out", torch.float32), _stream()), "ada_blend_fwd")
 
 
 def selftest() -> int:

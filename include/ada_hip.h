@@ -185,6 +185,20 @@ int ada_bilinear_fwd(const float* in, int64_t ld_in, int32_t batch, int32_t hi, 
                      float* out_f32, int64_t ld_f32, void* out_op, int64_t ld_op, int32_t map_op,
                      int32_t relu, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Device-side glue of the two-model pipeline of infer.py (kept in HBM instead of bouncing through numpy):
+ *   ada_minmax_fwd     per-image min / max of a [B, n] fp32 map -> minmax[B, 2]          (infer.py:22)
+ *   ada_normalize_fwd  norm = (d - min) / (max - min) and/or obs = norm * 2 - 1          (infer.py:22,92)
+ *   ada_blend_fwd      out = mask > 0 ? amodal : base, then a 3x3 box blur (reflect-101 borders, = cv2.blur)
+ *                      on the pixels whose 3x3 mask neighbourhood is mixed                (infer.py:30-44)
+ * all tensors fp32, [B, H, W] contiguous; mask is 0/1 (anything > 0 counts as inside).
+ * ---------------------------------------------------------------------------------------- */
+int ada_minmax_fwd(const float* in, int32_t batch, int64_t n_per_image, float* minmax, void* stream);
+int ada_normalize_fwd(const float* in, const float* minmax, int32_t batch, int64_t n_per_image, float* norm,
+                      float* obs, void* stream);
+int ada_blend_fwd(const float* amodal, const float* base, const float* mask, int32_t batch, int32_t height,
+                  int32_t width, float* out, void* stream);
+
 /* Hardware self-test used by the GPU test-suite: checks the MFMA / LDS-transpose fragment layouts the
  * kernels assume against a scalar computation on the device.  Returns 0 when they hold,
  * a positive bit mask of failed probes otherwise.  scratch: >= 1 MiB of device memory. */

@@ -98,11 +98,36 @@ def load_models(device="cuda", raw_weights=None, amodal_weights=None, raw_encode
     return model_raw, amodal
 
 
+def _on_device_pipeline(image_bgr, amodal_mask, model_raw, depth_amodal_model, device):
+    """Both networks + min-max normalise + blend without leaving the GPU (hip_ext.pipeline); same arithmetic as the host path."""
+    from hip_ext.pipeline import amodal_depth_pipeline
+    img518 = resize_bilinear_u8(image_bgr, 518, 518)
+    rgb_raw = (torch.tensor(img518).permute(2, 0, 1).unsqueeze(0) / 255).to(device)
+    rgb = F.interpolate(torch.tensor(image_bgr).unsqueeze(0).permute(0, 3, 1, 2) / 255, size=(518, 518), mode="nearest").float().to(device)
+    mask_ts = (F.interpolate(torch.tensor(amodal_mask).float()[None, None], size=(518, 518), mode="nearest") > 0).float().to(device)
+    base_norm, _, blended = amodal_depth_pipeline(model_raw, depth_amodal_model, rgb, mask_ts, rgb_raw=rgb_raw)
+    return base_norm[0].cpu(), blended[0].cpu()
+
+
 def infer_single_image(input_image_path, input_mask_path, output_path, model_raw, depth_amodal_model, device="cuda"):
     file_name = os.path.basename(input_image_path).split(".")[0]
     os.makedirs(output_path, exist_ok=True)
     image_bgr = imread_bgr(input_image_path)
     h0, w0 = image_bgr.shape[:2]
+    if str(device).startswith("cuda"):
+        amodal_mask = np.asarray(Image.open(input_mask_path)) > 0
+        if amodal_mask.ndim == 3:
+            amodal_mask = amodal_mask.any(-1)
+        base_depth, depth_agg = _on_device_pipeline(image_bgr, amodal_mask, model_raw, depth_amodal_model, device)
+        raw_colored = (colorize_depth_maps(base_depth.numpy(), 0, 1, cmap="Spectral_r").squeeze() * 255).astype(np.uint8)
+        raw_colored_hwc = resize_nearest(chw2hwc(raw_colored), w0, h0)
+        mask518 = (F.interpolate(torch.tensor(amodal_mask).float()[None, None], (518, 518)).squeeze().numpy() > 0).astype(np.uint8) * 255
+        agg_colored = (colorize_depth_maps(depth_agg.numpy(), 0, 1, cmap="Spectral_r").squeeze() * 255).astype(np.uint8)
+        agg_colored_hwc = resize_nearest(highlight_target(chw2hwc(agg_colored), mask518), w0, h0)
+        raw_out, agg_out = raw_colored_hwc[:, :, [2, 1, 0]], agg_colored_hwc[:, :, [2, 1, 0]]
+        imwrite_bgr(os.path.join(output_path, f"{file_name}_raw_depth_rendered.png"), raw_out)
+        imwrite_bgr(os.path.join(output_path, f"{file_name}_amodal_depth_rendered.png"), agg_out)
+        return raw_out, agg_out
     base_depth, raw_colored_hwc = predict_base_depth(image_bgr, model_raw, device)
     raw_colored_hwc = resize_nearest(raw_colored_hwc, w0, h0)
 

@@ -300,3 +300,30 @@ def test_errors_are_reported_not_thrown(hip):
         hip.igemm(M=64, N=64, K=64, A=A.cpu(), lda=64, W=A, out_f32=out, ldo_f32=64)
     with pytest.raises(hip.HipExtError, match="multiple of the 14-pixel patch"):
         hip.patchify(torch.zeros(1, 3, 30, 28, device=DEV), None, 1, 0, 30, 28, None, None, torch.zeros(4, 640, dtype=op, device=DEV), 640)
+
+
+def test_pipeline_glue_kernels(hip):
+    """min/max, normalise, paste + border blur against the host restatement used by infer.py."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import infer
+    B, H, W = 3, 37, 53
+    d = _rand(B, H, W, seed=50).abs() * 3
+    mm = torch.zeros(B, 2, device=DEV)
+    hip.minmax(d.to(DEV), mm)
+    assert torch.equal(mm.cpu()[:, 0], d.reshape(B, -1).min(1).values) and torch.equal(mm.cpu()[:, 1], d.reshape(B, -1).max(1).values)
+    norm, obs = torch.zeros(B, H, W, device=DEV), torch.zeros(B, 1, H, W, device=DEV)
+    hip.normalize(d.to(DEV), mm, norm=norm, obs=obs)
+    ref = (d - d.reshape(B, -1).min(1).values.view(B, 1, 1)) / (d.reshape(B, -1).max(1).values - d.reshape(B, -1).min(1).values).view(B, 1, 1)
+    assert torch.allclose(norm.cpu(), ref, atol=1e-6) and torch.allclose(obs.cpu()[:, 0], ref * 2 - 1, atol=1e-6)
+    am = torch.rand(B, H, W, generator=torch.Generator().manual_seed(51))
+    mask = torch.zeros(B, H, W)
+    mask[0, 5:20, 10:30] = 1
+    mask[1, :, :7] = 1          # touches the image border: exercises reflect-101
+    mask[2, 30:, 40:] = 1
+    out = torch.zeros(B, H, W, device=DEV)
+    hip.blend(am.to(DEV), ref.contiguous().to(DEV), mask.to(DEV), out)
+    for b in range(B):
+        want = infer.median_filter_blend(am[b], ref[b].clone(), mask[b].numpy())
+        assert torch.allclose(out[b].cpu(), want, atol=1e-6), float((out[b].cpu() - want).abs().max())

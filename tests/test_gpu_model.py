@@ -141,3 +141,37 @@ def test_infer_cli_end_to_end_on_gpu(hip, tmp_path):
     for suffix in ("raw_depth_rendered", "amodal_depth_rendered"):
         im = Image.open(tmp_path / "out" / f"img_{suffix}.png")
         assert im.size == (120, 90)
+
+
+def test_on_device_pipeline_matches_host_composition(hip):
+    """hip_ext.pipeline (both nets + normalise + blend on the GPU) == the host-side composition of reference infer.py."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import infer
+    from hip_ext.pipeline import amodal_depth_pipeline
+    raw_case = dict(kind="raw", encoder="vits", features=64, out_channels=[48, 96, 192, 384])
+    am_case = dict(kind="amodal", encoder="vits", guide_type="mask+observation", loss="entire_target_object")
+    raw = build_product_model(raw_case)
+    raw.load_state_dict(synth_state_dict(raw), strict=True)
+    am = build_product_model(am_case)
+    am.load_state_dict(synth_state_dict(am), strict=True)
+    raw, am = raw.cuda(), am.cuda()
+    g = torch.Generator().manual_seed(7)
+    rgb = torch.rand(2, 3, 126, 154, generator=g).cuda()
+    mask = torch.zeros(2, 1, 126, 154)
+    mask[0, :, 20:80, 30:100] = 1
+    mask[1, :, :40, :] = 1
+    base_norm, pred, out = amodal_depth_pipeline(raw, am, rgb, mask.cuda())
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1).cuda()
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1).cuda()
+    with torch.no_grad():
+        base = raw((rgb - mean) / std).cpu()
+    for b in range(2):
+        bn = (base[b] - base[b].min()) / (base[b].max() - base[b].min())
+        assert torch.allclose(base_norm[b].cpu(), bn, atol=1e-6)
+        with torch.no_grad():
+            p = am(rgb[b:b + 1], guide_rgb=None, guide_mask=mask[b:b + 1].cuda() * 2 - 1, observation=(bn[None, None].cuda() * 2 - 1)).cpu()[0, 0]
+        assert torch.allclose(pred[b].cpu(), p, atol=1e-5)
+        want = infer.median_filter_blend(p, bn.clone(), mask[b, 0].numpy())
+        assert torch.allclose(out[b].cpu(), want, atol=1e-5)

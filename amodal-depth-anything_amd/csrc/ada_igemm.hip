@@ -59,9 +59,7 @@ struct IgemmDev {
     int tail_act;
     int tiles_m, tiles_n;
     int cps;  // k-steps per conv tap = lda / 64
-    int sched;  // main-loop schedule (ADA_IGEMM_SCHED, see the kernel)
     unsigned long long* dbg;  // optional per-block timestamps (ada_debug_set_timestamps)
-    int skew;   // first-round blocks on odd CUs sleep skew*8k cycles so CUs run out of phase (epilogue bursts overlap MFMA)
 };
 
 // exact-erf GELU (nn.GELU default, reference mlp.py:23).  erf through the Abramowitz-Stegun 7.1.26 rational form
@@ -214,137 +212,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
         slab_offsets(0, aoff, boff);
         stage_part(0, aoff, boff, -1);
     }
-    if (NWAVES == 8 && p.sched == 5) {
-        // schedule 5 ("ping-pong"): the two waves that share a SIMD (wave w and w+4) run half a k-step apart, and each
-        // wave's MFMA phase is software-pipelined by hand.  A k-step has two barrier intervals:
-        //     P1  data movement only: first fragment reads of the slab (+ for group 1 its global->LDS copies of slab t+1)
-        //     P2  NSUB x (TI*TJ) MFMAs; the fragment reads of sub-step s+1 are issued before the MFMAs of sub-step s and
-        //         waited for with a counted lgkmcnt (group 0 also issues its copies of slab t+1 here)
-        //   physical barrier #:   1        2        3        4
-        //   group 0 (waves 0-3):  P1(0) | P2(0) | P1(1) | P2(1) | ...
-        //   group 1 (waves 4-7):  (x)   | P1(0) | P2(0) | P1(1) | ...
-        // so one wave per SIMD is always in its MFMA phase while its partner moves data.  LDS hazards: slab t+1 goes into
-        // the buffer of slab t-1; group 0 copies inside P2(t) (group 1 finished P2(t-1) at the barrier before), group 1 at
-        // the start of its P1(t) (same interval); both wait for their own copies (vmcnt(0)) before the barrier that ends
-        // the interval, after which group 0 starts P1(t+1).
-        const int grp = wave >> 2;
-        const unsigned lds0 = (unsigned)(size_t)smem;
-        unsigned cofs[NSUB];
-#pragma unroll
-        for (int s2 = 0; s2 < NSUB; ++s2) cofs[s2] = ((2 * s2 + hi) ^ swz) * 16;
-        const unsigned a_base = lds0 + a_row_off, b_base = lds0 + b_row_off;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (p.dbg) t_first = __builtin_amdgcn_s_memtime();
-        if (grp == 1) __builtin_amdgcn_s_barrier();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            const bool more = kt + 1 < nk;
-            long aoff = 0, boff = 0;
-            if (more) slab_offsets(kt + 1, aoff, boff);
-            const unsigned sa = a_base + cur * STAGE_BYTES, sb = b_base + cur * STAGE_BYTES;
-            opx8 af[2][TI], bf[2][TJ];
-            auto issue = [&](int buf, int s2) {
-                const unsigned aa = sa + cofs[s2], bb = sb + cofs[s2];
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[buf][i]) : "v"(aa), "i"(i * 32 * RB));
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[buf][j]) : "v"(bb), "i"(j * 32 * RB));
-            };
-            // ---- P1
-            if (grp == 1 && more) stage_part(cur ^ 1, aoff, boff, -1);
-            issue(0, 0);
-            if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- P2
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int s = 0; s < NSUB; ++s) {
-                if (s + 1 < NSUB) issue((s + 1) & 1, s + 1);
-                if (grp == 0 && more && s < 2) {
-                    stage_part(cur ^ 1, aoff, boff, (NSUB == 4) ? 2 * s : s);
-                    if (NSUB == 4) stage_part(cur ^ 1, aoff, boff, 2 * s + 1);
-                }
-                if (s > 0) {   // fragments of sub-step 0 were waited for in P1
-                    if (s + 1 < NSUB) {
-                        if constexpr (TI + TJ == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-                        else if constexpr (TI + TJ == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    } else {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(af[s & 1][i], bf[s & 1][j], acc[i][j]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_s_setprio(0);
-            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (grp == 0) __builtin_amdgcn_s_barrier();
-    } else if (p.sched == 4) {
-        // schedule 4: hand-counted LDS pipeline.  Fragment reads are inline-asm ds_read_b128 (invisible to hipcc's
-        // s_waitcnt pass, which otherwise drains lgkmcnt(0) in front of every MFMA cluster and exposes the LDS latency);
-        // the reads of sub-step s+1 are issued before the wait for sub-step s, which is a COUNTED lgkmcnt(TI+TJ): LDS
-        // returns in order, so the older TI+TJ reads are complete while the newer ones stay in flight behind the MFMAs.
-        const unsigned lds0 = (unsigned)(size_t)smem;
-        unsigned cofs[NSUB];
-#pragma unroll
-        for (int s2 = 0; s2 < NSUB; ++s2) cofs[s2] = ((2 * s2 + hi) ^ swz) * 16;
-        const unsigned a_base = lds0 + a_row_off, b_base = lds0 + b_row_off;
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (p.dbg && kt == 0) t_first = __builtin_amdgcn_s_memtime();
-            const bool more = kt + 1 < nk;
-            long aoff = 0, boff = 0;
-            if (more) slab_offsets(kt + 1, aoff, boff);
-            const unsigned sa = a_base + cur * STAGE_BYTES, sb = b_base + cur * STAGE_BYTES;
-            opx8 af[2][TI], bf[2][TJ];
-            auto issue = [&](int buf, int s2) {
-                const unsigned aa = sa + cofs[s2], bb = sb + cofs[s2];
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[buf][i]) : "v"(aa), "i"(i * 32 * RB));
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[buf][j]) : "v"(bb), "i"(j * 32 * RB));
-            };
-            issue(0, 0);
-#pragma unroll
-            for (int s = 0; s < NSUB; ++s) {
-                if (s + 1 < NSUB) issue((s + 1) & 1, s + 1);
-                if (more) stage_part(cur ^ 1, aoff, boff, s);
-                if (s + 1 < NSUB) {
-                    if constexpr (TI + TJ == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-                    else if constexpr (TI + TJ == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                    else if constexpr (TI + TJ == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(af[s & 1][i], bf[s & 1][j], acc[i][j]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    } else {
-        // schedule 0: all copies of slab t+1 issued right after the barrier, compiler-scheduled fragment reads
+    {
+        // All copies of slab t+1 are issued right after the barrier; fragment reads are scheduled by the compiler.
+        // (Hand-counted lgkmcnt pipelines and a ping-pong split of the two waves per SIMD were tried and measured: fewer
+        // cycles per k-step but no wall-clock gain on this power-limited kernel -- profiles/r01_c_gemm_sched{4,5}_ab.txt.)
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             unsigned long long tw0 = 0, tw1 = 0;
@@ -738,11 +609,10 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
 }  // namespace
 
 static unsigned long long* g_dbg = nullptr;
-static int g_force_tile = -1, g_sched = 0, g_short_k_cfg = 3;
+static int g_force_tile = -1, g_short_k_cfg = 3;
 static bool g_env_read = false;
-// debug hooks (not part of the stable ABI): override the tile configuration (-1 = heuristic) / main-loop schedule
+// debug hook (not part of the stable ABI): override the tile configuration (-1 = heuristic)
 extern "C" void ada_debug_set_tile(int cfg) { g_force_tile = cfg; g_env_read = true; }
-extern "C" void ada_debug_set_sched(int sched) { g_sched = sched; }
 // debug hook (not part of the stable ABI): device buffer of 8 x u64 per workgroup, or NULL to disable
 extern "C" void ada_debug_set_timestamps(void* dev_buf) { g_dbg = (unsigned long long*)dev_buf; }
 
@@ -832,14 +702,10 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
         g_env_read = true;
         const char* e = getenv("ADA_IGEMM_TILE");
         g_force_tile = e ? atoi(e) : -1;
-        const char* sc = getenv("ADA_IGEMM_SCHED");
-        g_sched = sc ? atoi(sc) : 0;
         const char* sk = getenv("ADA_IGEMM_SHORTK");
         g_short_k_cfg = sk ? atoi(sk) : 3;
     }
     const int force = g_force_tile, short_k_cfg = g_short_k_cfg;
-    d.sched = g_sched;
-    d.skew = 0;
     d.dbg = g_dbg;
     hipStream_t s = (hipStream_t)stream;
     if (tail) return launch_epi<EPI_TAIL>(d, s, a->N <= 32 ? 0 : 1, 3);

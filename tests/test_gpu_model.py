@@ -175,3 +175,37 @@ def test_on_device_pipeline_matches_host_composition(hip):
         assert torch.allclose(pred[b].cpu(), p, atol=1e-5)
         want = infer.median_filter_blend(p, bn.clone(), mask[b, 0].numpy())
         assert torch.allclose(out[b].cpu(), want, atol=1e-5)
+
+
+def test_large_batches_are_chunked_and_repeatable(hip, monkeypatch):
+    """Batches whose pixel count exceeds the kernels' row-index limit are split internally; results equal the unsplit run
+    bit for bit, and repeated calls are deterministic (no atomics / split-K anywhere on the path)."""
+    from hip_ext import engine as E
+    _, meta = load_golden("vits_g_observation")
+    case = dict(meta["case"], B=3)
+    model = build_product_model(case)
+    model.load_state_dict(synth_state_dict(model, meta), strict=True)
+    x, grgb, mask, obs = case_inputs(case)
+    full = _run_product(model, case, x, grgb, mask, obs)
+    again = _run_product(model, case, x, grgb, mask, obs)
+    assert torch.equal(full, again)
+    monkeypatch.setattr(E, "MAX_ROWS", case["H"] * case["W"] * 2)     # forces chunks of 2 + 1 images
+    split = _run_product(model, case, x, grgb, mask, obs)
+    assert torch.equal(full, split)
+
+
+def test_runs_on_a_side_stream(hip):
+    """Kernels are launched on torch's *current* stream: the forward works (and is ordered) on a non-default stream."""
+    _, meta = load_golden("vits_g_mask")
+    case = meta["case"]
+    model = build_product_model(case)
+    model.load_state_dict(synth_state_dict(model, meta), strict=True)
+    x, grgb, mask, obs = case_inputs(case)
+    ref = _run_product(model, case, x, grgb, mask, obs)
+    s = torch.cuda.Stream()
+    xc, mc = x.cuda(), mask.cuda()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s), torch.no_grad():
+        out = model(xc, guide_rgb=None, guide_mask=mc, observation=None)
+    s.synchronize()
+    assert torch.equal(out.cpu(), ref)

@@ -59,6 +59,7 @@ struct IgemmDev {
     int tail_act;
     int tiles_m, tiles_n;
     int cps;  // k-steps per conv tap = lda / 64
+    int variant;  // main-loop variant for A/B runs (ada_debug_set_variant)
     unsigned long long* dbg;  // optional per-block timestamps (ada_debug_set_timestamps)
 };
 
@@ -229,11 +230,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
                 t_bar += tw2 - tw1;
             }
             if (p.dbg && kt == 0) t_first = __builtin_amdgcn_s_memtime();
-            if (kt + 1 < nk) {
-                long aoff, boff;
-                slab_offsets(kt + 1, aoff, boff);
-                stage_part(cur ^ 1, aoff, boff, -1);
-            }
+            // The two waves that share a SIMD (w and w+4 of an 8-wave workgroup) leave the barrier together; if both issued
+            // their global->LDS copies first, neither would have MFMAs in flight for ~500 cycles.  Variant 1 (default, +3 %
+            // measured: profiles/r01_e_gemm_stagger_ab.txt) staggers them: waves 0-3 copy before their MFMAs, waves 4-7
+            // half-way through (their copies still have half a k-step to land; later than that loses again).
+            const bool late = (NWAVES == 8) && (p.variant >= 1) && (wave >= 4);
+            const int late_at = (p.variant == 2) ? NSUB / 2 : NSUB / 2 - 1;
+            const bool more = kt + 1 < nk;
+            long aoff = 0, boff = 0;
+            if (more) slab_offsets(kt + 1, aoff, boff);
+            if (more && !late) stage_part(cur ^ 1, aoff, boff, -1);
             const char* sbase = smem + cur * STAGE_BYTES;
 #pragma unroll
             for (int s = 0; s < NSUB; ++s) {
@@ -247,6 +253,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+                if (s == late_at) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more && late) stage_part(cur ^ 1, aoff, boff, -1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
@@ -609,10 +620,11 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
 }  // namespace
 
 static unsigned long long* g_dbg = nullptr;
-static int g_force_tile = -1, g_short_k_cfg = 3;
+static int g_force_tile = -1, g_short_k_cfg = 3, g_variant = 1;
 static bool g_env_read = false;
 // debug hook (not part of the stable ABI): override the tile configuration (-1 = heuristic)
 extern "C" void ada_debug_set_tile(int cfg) { g_force_tile = cfg; g_env_read = true; }
+extern "C" void ada_debug_set_variant(int v) { g_variant = v; }
 // debug hook (not part of the stable ABI): device buffer of 8 x u64 per workgroup, or NULL to disable
 extern "C" void ada_debug_set_timestamps(void* dev_buf) { g_dbg = (unsigned long long*)dev_buf; }
 
@@ -702,11 +714,14 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
         g_env_read = true;
         const char* e = getenv("ADA_IGEMM_TILE");
         g_force_tile = e ? atoi(e) : -1;
+        const char* va = getenv("ADA_IGEMM_VARIANT");
+        if (va) g_variant = atoi(va);
         const char* sk = getenv("ADA_IGEMM_SHORTK");
         g_short_k_cfg = sk ? atoi(sk) : 3;
     }
     const int force = g_force_tile, short_k_cfg = g_short_k_cfg;
     d.dbg = g_dbg;
+    d.variant = g_variant;
     hipStream_t s = (hipStream_t)stream;
     if (tail) return launch_epi<EPI_TAIL>(d, s, a->N <= 32 ? 0 : 1, 3);
     if (swiglu) return launch_epi<EPI_SWIGLU>(d, s, force, short_k_cfg);

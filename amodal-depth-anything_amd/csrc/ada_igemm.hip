@@ -60,6 +60,7 @@ struct IgemmDev {
     int tiles_m, tiles_n;
     int cps;  // k-steps per conv tap = lda / 64
     int variant;  // main-loop variant for A/B runs (ada_debug_set_variant)
+    int group_n;  // tile order: N-tiles are walked in column groups of this width (== tiles_n: plain row-major)
     unsigned long long* dbg;  // optional per-block timestamps (ada_debug_set_timestamps)
 };
 
@@ -128,8 +129,21 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
         const int q = nblk >> 3, r = nblk & 7;
         const int xcd = bid & 7, idx = bid >> 3;
         const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        tm = logical / p.tiles_n;
-        tn = logical - tm * p.tiles_n;
+        // column-group-major order: all M-panels of a group of `group_n` N-tiles before the next group, so the group's
+        // weight slabs stay resident in the XCD's 4 MiB L2 instead of being re-streamed every round of tiles
+        const int gn = p.group_n;
+        const int full = p.tiles_n / gn;              // number of full-width groups
+        const int per_group = p.tiles_m * gn;
+        if (logical < full * per_group) {
+            const int g = logical / per_group, rr = logical - g * per_group;
+            tm = rr / gn;
+            tn = g * gn + (rr - tm * gn);
+        } else {
+            const int gl = p.tiles_n - full * gn;     // width of the last, narrower group
+            const int rr = logical - full * per_group;
+            tm = rr / gl;
+            tn = full * gn + (rr - tm * gl);
+        }
     }
     const int m0 = tm * BM, n0 = tn * BN;
     unsigned long long t_entry = 0, t_first = 0, t_loop = 0, t_vm = 0, t_bar = 0;
@@ -550,12 +564,30 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
     }
 }
 
+static int g_group_override = 0;  // debug: force the column-group width (0 = model)
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
 int launch_cfg(IgemmDev& d, hipStream_t stream) {
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int SMEM = 2 * (BM + BN) * BK * 2;
     d.tiles_m = (d.M + BM - 1) / BM;
     d.tiles_n = (d.N + BN - 1) / BN;
+    {
+        // L2 traffic model (bytes missing the XCD L2s): row-major re-streams W once per XCD per round of tiles when W exceeds
+        // the L2; column groups of width g keep g weight slabs resident but re-read the A panels once per group.
+        const double a_bytes = (double)d.M * (d.a_mode == ADA_A_PLAIN ? d.K : d.lda) * 2.0;
+        const double slab = (double)BN * d.K * 2.0, w_bytes = slab * d.tiles_n;
+        const double rounds = (double)(((long)d.tiles_m * d.tiles_n + 255) / 256);
+        double best = a_bytes + (w_bytes > 3.0e6 ? rounds * 8.0 * w_bytes : 8.0 * w_bytes);
+        int gbest = d.tiles_n;
+        for (int g = 1; g < d.tiles_n; ++g) {
+            if (g * slab > 2.6e6 && g > 1) break;
+            const double groups = (double)((d.tiles_n + g - 1) / g);
+            const double est = groups * a_bytes + 8.0 * w_bytes;
+            if (est < 0.9 * best) { best = est; gbest = g; }
+        }
+        d.group_n = g_group_override > 0 ? (g_group_override < d.tiles_n ? g_group_override : d.tiles_n) : gbest;
+    }
     auto kern = igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -625,6 +657,7 @@ static bool g_env_read = false;
 // debug hook (not part of the stable ABI): override the tile configuration (-1 = heuristic)
 extern "C" void ada_debug_set_tile(int cfg) { g_force_tile = cfg; g_env_read = true; }
 extern "C" void ada_debug_set_variant(int v) { g_variant = v; }
+extern "C" void ada_debug_set_group(int g) { g_group_override = g; }
 // debug hook (not part of the stable ABI): device buffer of 8 x u64 per workgroup, or NULL to disable
 extern "C" void ada_debug_set_timestamps(void* dev_buf) { g_dbg = (unsigned long long*)dev_buf; }
 
@@ -707,6 +740,7 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.dShS = make_fastdiv(a->shuffle_s > 0 ? a->shuffle_s : 1);
     d.tail_w = a->tail_w; d.tail_b = a->tail_b; d.tail_act = a->tail_act;
     d.cps = 0;
+    d.group_n = 1;
     d.tiles_m = d.tiles_n = 0;
 
     // A/B switches for kernel experiments (read once): tile override, main-loop schedule, tile used for short k-loops
@@ -714,6 +748,8 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
         g_env_read = true;
         const char* e = getenv("ADA_IGEMM_TILE");
         g_force_tile = e ? atoi(e) : -1;
+        const char* gr = getenv("ADA_IGEMM_GROUP");
+        if (gr) g_group_override = atoi(gr);
         const char* va = getenv("ADA_IGEMM_VARIANT");
         if (va) g_variant = atoi(va);
         const char* sk = getenv("ADA_IGEMM_SHORTK");

@@ -150,8 +150,11 @@ def main():
                                               "share_of_step": at["ms_total"] / (1e3 * dt)}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and "roofline" in line:
-            try:
-                line["roofline"]["traffic"] = json.load(open(pmc)).get("igemm_bytes_per_launch")
+            try:  # HBM/L2-fabric bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json)
+                t = json.load(open(pmc))
+                line["roofline"]["traffic"] = t.get("igemm_bytes_per_launch")
+                if "roofline_attention" in line:
+                    line["roofline_attention"]["traffic"] = t.get("attention_bytes_per_launch")
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:

@@ -108,13 +108,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
 // one workgroup per patch row; a thread handles column pairs (dx, dx+1) of the same (c, dy)
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, const float* __restrict__ guide, int cg,
                                                        int H, int W, int ph, int pw, float3 mean, float3 inv_std, int normalise,
-                                                       op_t* __restrict__ out, long ld) {
+                                                       op_t* __restrict__ out, long ld, int seg) {
     const int p = blockIdx.x;  // (b, py, px)
     const int px = p % pw;
     const int py = (p / pw) % ph;
     const int b = p / (pw * ph);
     const int kreal = (3 + cg) * 196;
-    for (int pair = threadIdx.x; pair * 2 < ld; pair += blockDim.x) {
+    // seg == 0: one segment of ld columns.  seg > 0 (split precision): three segments of `seg` columns holding
+    // [hi | lo | hi] with hi = round(x), lo = round(x - hi): paired with weights [w_hi | w_hi | w_lo] one GEMM computes
+    // x_hi w_hi + x_lo w_hi + x_hi w_lo, i.e. the patch embedding to ~fp32 accuracy from fp16 MFMAs.
+    const int width = seg > 0 ? seg : (int)ld;
+    for (int pair = threadIdx.x; pair * 2 < width; pair += blockDim.x) {
         const int col = pair * 2;
         float a0 = 0.f, a1 = 0.f;
         if (col < kreal) {
@@ -140,6 +144,13 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
         o[0] = to_op(a0);
         o[1] = to_op(a1);
         *(opx2*)(out + (long)p * ld + col) = o;
+        if (seg > 0) {
+            opx2 lo;
+            lo[0] = to_op(a0 - (float)o[0]);
+            lo[1] = to_op(a1 - (float)o[1]);
+            *(opx2*)(out + (long)p * ld + seg + col) = lo;
+            *(opx2*)(out + (long)p * ld + 2 * seg + col) = o;
+        }
     }
 }
 
@@ -237,12 +248,14 @@ extern "C" int ada_layernorm_fwd(const float* in, int64_t ld_in, int32_t rows_ou
 }
 
 extern "C" int ada_patchify(const float* x, const float* guide, int32_t batch, int32_t cg, int32_t height, int32_t width,
-                            const float* mean, const float* inv_std, void* out, int64_t ld, void* stream) {
+                            const float* mean, const float* inv_std, void* out, int64_t ld, int32_t split, void* stream) {
     ADA_REQUIRE(x && out, ADA_EINVAL, "ada_patchify: null pointer");
     ADA_REQUIRE(cg == 0 || guide, ADA_EINVAL, "ada_patchify: guide channels without guide tensor");
     ADA_REQUIRE(batch > 0 && cg >= 0 && height > 0 && width > 0, ADA_EINVAL, "ada_patchify: bad shape");
     ADA_REQUIRE(height % 14 == 0 && width % 14 == 0, ADA_EINVAL, "ada_patchify: %dx%d is not a multiple of the 14-pixel patch", height, width);
     ADA_REQUIRE(ld % 2 == 0 && ld >= (3 + cg) * 196, ADA_EINVAL, "ada_patchify: ld=%ld too small", (long)ld);
+    ADA_REQUIRE(split == 0 || split == 1, ADA_EINVAL, "ada_patchify: split must be 0 or 1");
+    ADA_REQUIRE(!split || (ld % 6 == 0 && ld / 3 >= (3 + cg) * 196), ADA_EINVAL, "ada_patchify: split needs ld = 3 * segment, segment >= (3+cg)*196");
     ADA_REQUIRE((mean == nullptr) == (inv_std == nullptr), ADA_EINVAL, "ada_patchify: mean and inv_std go together");
     float3 mu = make_float3(0.f, 0.f, 0.f), is = make_float3(1.f, 1.f, 1.f);
     if (mean) {  // host pointers: three floats each
@@ -251,7 +264,7 @@ extern "C" int ada_patchify(const float* x, const float* guide, int32_t batch, i
     }
     const int ph = height / 14, pw = width / 14;
     hipLaunchKernelGGL(patchify_kernel, dim3(batch * ph * pw), dim3(256), 0, (hipStream_t)stream, x, guide, cg, height, width, ph, pw,
-                       mu, is, mean ? 1 : 0, (op_t*)out, (long)ld);
+                       mu, is, mean ? 1 : 0, (op_t*)out, (long)ld, split ? (int)(ld / 3) : 0);
     return ada_check_launch("ada_patchify");
 }
 

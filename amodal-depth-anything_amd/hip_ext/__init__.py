@@ -87,7 +87,7 @@ def load(path: Optional[str] = None):
                                       c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p]
     lib.ada_layernorm_fwd.restype = c_int
     lib.ada_patchify.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
-                                 ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p, c_int64, c_void_p]
+                                 ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p, c_int64, c_int32, c_void_p]
     lib.ada_patchify.restype = c_int
     lib.ada_write_cls.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
     lib.ada_write_cls.restype = c_int
@@ -216,7 +216,7 @@ def layernorm(inp, ld_in, rows_out, dim, weight, bias, eps, *, group_in=0, skip=
                                     _opt(out_f32, "out_f32", torch.float32), ld_f32, _stream()), "ada_layernorm_fwd")
 
 
-def patchify(x, guide, batch, cg, height, width, mean, inv_std, out, ld):
+def patchify(x, guide, batch, cg, height, width, mean, inv_std, out, ld, split=False):
     op = operand_dtype()
     if mean is not None:
         m = (c_float * 3)(*mean)
@@ -224,7 +224,7 @@ def patchify(x, guide, batch, cg, height, width, mean, inv_std, out, ld):
     else:
         m = s = None
     _check(load().ada_patchify(_dev(x, "x", torch.float32), _opt(guide, "guide", torch.float32), batch, cg, height, width,
-                               m, s, _dev(out, "out", op), ld, _stream()), "ada_patchify")
+                               m, s, _dev(out, "out", op), ld, int(split), _stream()), "ada_patchify")
 
 
 def write_cls(tokens, batch, n_tokens, dim, cls, pos0):

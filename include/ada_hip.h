@@ -161,12 +161,15 @@ int ada_layernorm_fwd(const float* in, int64_t ld_in, int32_t rows_out, int32_t 
  * the ImageNet normalisation of src/models/amodalsynthdrive/dav2.py:65 fused in.
  * x: fp32 NCHW [B,3,H,W]; guide: fp32 NCHW [B,Cg,H,W] or NULL (Cg = 0).
  * out: op-typed [B*(H/14)*(W/14), ld] with column (c*196 + dy*14 + dx), c over RGB then guide
- * channels; columns >= (3+Cg)*196 are written as zero.  mean/inv_std: [3] fp32 or NULL (raw model,
- * already normalised by the caller: infer.py:19).
+ * channels; columns >= (3+Cg)*196 are written as zero.  mean/inv_std: [3] fp32 HOST pointers or NULL (raw
+ * model, already normalised by the caller: infer.py:19).
+ * split = 1 (split-precision embed): ld = 3 * segment and the row holds [hi | lo | hi], hi = round_op(x),
+ * lo = round_op(x - hi); with weights packed as [w_hi | w_hi | w_lo] the following GEMM evaluates the patch
+ * embedding to ~fp32 accuracy on the fp16 matrix cores (3x the MACs of a layer that is 0.2 % of the model).
  * ---------------------------------------------------------------------------------------- */
 int ada_patchify(const float* x, const float* guide, int32_t batch, int32_t cg, int32_t height,
                  int32_t width, const float* mean, const float* inv_std, void* out, int64_t ld,
-                 void* stream);
+                 int32_t split, void* stream);
 
 /* cls row of the token matrix: tokens[b, 0, :] = cls + pos[0]  (DA2/dinov2.py:245-246). */
 int ada_write_cls(float* tokens, int32_t batch, int32_t n_tokens, int32_t dim, const float* cls,

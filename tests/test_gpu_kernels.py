@@ -327,3 +327,31 @@ def test_pipeline_glue_kernels(hip):
     for b in range(B):
         want = infer.median_filter_blend(am[b], ref[b].clone(), mask[b].numpy())
         assert torch.allclose(out[b].cpu(), want, atol=1e-6), float((out[b].cpu() - want).abs().max())
+
+
+def test_patchify_split_precision(hip):
+    """[hi | lo | hi] layout: hi + lo reproduces the fp32 pixel to ~2^-22, and a GEMM against [w_hi | w_hi | w_lo] matches fp32."""
+    op = _op(hip)
+    B, H, W, cg = 1, 28, 42, 2
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(60))
+    g = torch.rand(B, cg, H, W, generator=torch.Generator().manual_seed(61)) * 2 - 1
+    K = (3 + cg) * 196
+    seg = (K + 63) // 64 * 64
+    out = torch.zeros(B * 6, 3 * seg, dtype=op, device=DEV)
+    hip.patchify(x.to(DEV), g.to(DEV), B, cg, H, W, None, None, out, 3 * seg, split=True)
+    ref = F.unfold(torch.cat([x, g], 1), 14, stride=14).transpose(1, 2).reshape(B * 6, K)
+    o = out.float().cpu()
+    assert torch.equal(o[:, :K], o[:, 2 * seg:2 * seg + K])
+    rec = o[:, :K] + o[:, seg:seg + K]
+    tol = 1e-6 if op == torch.float16 else 1e-4
+    assert float((rec - ref).abs().max()) < tol
+    w = _rand(64, K, seed=62) * K ** -0.5
+    wp = torch.zeros(64, seg)
+    wp[:, :K] = w
+    w_hi = wp.to(op)
+    w_lo = (wp - w_hi.float()).to(op)
+    Wcat = torch.cat([w_hi, w_hi, w_lo], 1).contiguous().to(DEV)
+    y = torch.zeros(B * 6, 64, device=DEV)
+    hip.igemm(M=B * 6, N=64, K=3 * seg, A=out, lda=3 * seg, W=Wcat, out_f32=y, ldo_f32=64)
+    err = (y.cpu() - ref @ w.T).abs().max()
+    assert float(err) < (2e-5 if op == torch.float16 else 2e-3), float(err)

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const op_t* __restric
     // ---- Q fragments (B operand of S^T = K Q^T): Q[q][16s + 8hi + j] ---------------------
     const int q_row = qb * QBLK + wave * 32 + l31;
     const int q_ld = q_row < n_tok ? q_row : n_tok - 1;
+    const bool wave_active = (qb * QBLK + wave * 32) < n_tok;   // wave-uniform
     opx8 qf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = *(const opx8*)(qptr + (long)q_ld * row_stride + 16 * s + 8 * hi);
@@ -147,6 +148,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const op_t* __restric
         const unsigned kbase_l = lds0 + cur * STAGE;
         const unsigned vbase0 = kbase_l + K_TILE + vofs[0], vbase1 = kbase_l + K_TILE + vofs[1];
 
+        // waves whose 32 query rows all lie beyond the sequence (last q-block only) keep copying and synchronising
+        // but skip the math
+        if (wave_active) {
         // ---- S^T = K Q^T - m -------------------------------------------------------------------
         opx8 kf[2][4];
 #pragma unroll
@@ -250,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const op_t* __restric
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        }  // wave_active
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

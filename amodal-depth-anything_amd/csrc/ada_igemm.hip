@@ -466,7 +466,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
         };
         // one-pass-ahead prefetch only where a single workgroup owns the CU; with 2-3 co-resident workgroups the other
         // workgroups' MFMAs already cover the latency and the 32 extra VGPRs would spill
-        constexpr bool AHEAD = NWAVES == 8;
+        constexpr bool AHEAD = NWAVES == 8 && TJ <= 2;
         float4 rcur[NKI], rnext[AHEAD ? NKI : 1];
 #pragma unroll
         for (int k = 0; k < NKI; ++k) rcur[k] = make_float4(0, 0, 0, 0);
@@ -601,7 +601,8 @@ int launch_cfg(IgemmDev& d, hipStream_t stream) {
     return ada_check_launch("ada_igemm");
 }
 
-// tile configurations: 0: 256x32, 1: 128x64, 2: 256x128, 3: 256x256 (1 WG/CU), 4: 128x128, 5: 128x256x32 (2-3 WG/CU)
+// tile configurations: 0: 256x32, 1: 128x64, 2: 256x128, 3: 256x256 (1 WG/CU), 4: 128x128, 5: 128x256x32 (2-3 WG/CU),
+// 7: 512x128 (8 waves x 64x128, all 160 KiB of LDS)
 // Relative time of launching `tiles` workgroups of a BMxBN tile with `occ` workgroups resident per CU and main-loop
 // efficiency `eff` (measured, relative to the 256x256 tile): whole rounds of 256*occ tiles, co-resident tiles share a CU.
 static inline double tile_time(long M, long N, int bm, int bn, int occ, double eff) {
@@ -617,7 +618,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
     int cfg;
     if (d.N <= 32) cfg = 0;
     else if (d.N <= 64) cfg = 1;
-    else if (d.N <= 128) cfg = 2;
+    else if (d.N <= 128) cfg = (d.M >= 512 * 512) ? 7 : 2;   // plenty of rows: the 512x128 tile stages fewer bytes per FLOP
     else {
         // large problems: the 256x256 tile (best MFMA efficiency); small ones (single images, ViT-S/B at small batch)
         // would leave most CUs idle with it, so pick the tile that minimises the quantised time estimate
@@ -644,6 +645,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
             case 2: return launch_cfg<256, 128, 64, 4, 2, EPI>(d, s);
             case 4: return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
             case 5: return launch_cfg<128, 256, 32, 2, 2, EPI>(d, s);
+            case 7: return launch_cfg<512, 128, 64, 8, 1, EPI>(d, s);
             default: return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
         }
     }

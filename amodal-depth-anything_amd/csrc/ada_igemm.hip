@@ -96,7 +96,7 @@ ADA_DEV opx4 pack4(float4 v) {
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmDev p) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && BM * BN == 256 * 256) ? 1 : 2) void igemm_kernel(IgemmDev p) {
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int NT = NWAVES * 64;
     constexpr int TI = BM / (WAVES_M * 32);
@@ -227,7 +227,104 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
         slab_offsets(0, aoff, boff);
         stage_part(0, aoff, boff, -1);
     }
-    {
+    // One wave per SIMD (4 waves, 128x128 wave tile, 256 accumulator registers in AGPRs): nobody else hides this wave's
+    // latencies, so the loop is software-pipelined by hand, three slabs deep:
+    //   slab kt    : in LDS stage kt&1, fragments double-buffered in registers (ds_reads of sub-step s+1 under the MFMAs of s)
+    //   slab kt+1  : in 16 staging registers per lane at the top of the k-step, written to the other LDS stage during
+    //                sub-steps 0-1 (ds_write_b128, lane-linear = the same swizzled layout the LDS-DMA path produces)
+    //   slab kt+2  : global_load_dwordx4 into each staging register right after it has been written out (a full k-step to land)
+    // Every filler instruction is slotted between two MFMAs (each holds the matrix pipe 32 cycles; <= 4 fillers per gap).
+    // LDS-DMA (global_load_lds) is not used here: with one wave per SIMD its m0 set-up and issue cost (~60 cycles each,
+    // 16 per k-step) is exposed -- measured 45 cycles per MFMA slot against 33-35 with register staging.
+    // The workgroup barrier sits before the last sub-step's MFMAs: by then every wave has written its part of slab kt+1 and
+    // holds its last fragments of slab kt in registers, so the first fragments of kt+1 are fetched under the last 16 MFMAs.
+    constexpr bool PIPE = (NWAVES == 4 && TI == 4 && TJ == 4 && BK == 64);
+    if constexpr (PIPE) {
+        static_assert(A_IT == 8 && B_IT == 8, "16 staging registers, 8 written per sub-step in sub-steps 0 and 1");
+        const unsigned lds0 = (unsigned)(size_t)smem;
+        unsigned aofs[NSUB], bofs[NSUB];
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const int coff = ((2 * s + hi) ^ swz) * 16;
+            aofs[s] = lds0 + a_row_off + coff;
+            bofs[s] = lds0 + b_row_off + coff;
+        }
+        opx8 fa[2][TI], fb[2][TJ];
+        // fragment read #r (0..7: a0 b0 a1 b1 ...) of sub-step s from the stage at byte offset sb, into register set `set`
+        auto rd1 = [&](int set, int s, unsigned sb, int r) {
+            const int t = r >> 1;
+            if (r & 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[set][t]) : "v"(bofs[s] + sb), "i"(t * 32 * RB));
+            else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[set][t]) : "v"(aofs[s] + sb), "i"(t * 32 * RB));
+        };
+        u32x4 g[A_IT + B_IT];
+        const unsigned wofs = lds0 + tid * 16;
+        auto gl = [&](int c, long aoff, long boff) {   // staging register c <- its 16 bytes of a slab
+            g[c] = c < A_IT ? *(const u32x4*)(a_ptr[c] + aoff) : *(const u32x4*)(b_ptr[c - A_IT] + boff);
+        };
+        auto wr = [&](int c, unsigned sb) {            // staging register c -> LDS stage at byte offset sb
+            if (c < A_IT) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(wofs + sb), "v"(g[c]), "i"(c * (NT * 16)));
+            else asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(wofs + sb), "v"(g[c]), "i"(A_BYTES + (c - A_IT) * (NT * 16)));
+        };
+        {
+            long aoff, boff;
+            slab_offsets(0, aoff, boff);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) gl(c, aoff, boff);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) wr(c, 0u);
+            slab_offsets(nk > 1 ? 1 : 0, aoff, boff);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) gl(c, aoff, boff);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (p.dbg) t_first = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) rd1(0, 0, 0u, r);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            long aoff, boff;
+            slab_offsets(kt + 2 < nk ? kt + 2 : nk - 1, aoff, boff);   // past the end: re-load the last slab (never consumed)
+            const unsigned sb = (unsigned)(cur * STAGE_BYTES), sbn = (unsigned)((cur ^ 1) * STAGE_BYTES);
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) {
+                const int set = s & 1;
+                // fragments of this sub-step have landed; the 4 ds_writes slotted after them may still be in flight
+                if (s == 1 || s == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (s == NSUB - 1) {
+                    unsigned long long tw0 = 0;
+                    if (p.dbg) tw0 = __builtin_amdgcn_s_memtime();
+                    __syncthreads();   // slab kt+1 is complete in LDS, stage `cur` is drained
+                    if (p.dbg) t_bar += __builtin_amdgcn_s_memtime() - tw0;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int i = q >> 2, j = q & 3;
+                    acc[i][j] = mfma32(fa[set][i], fb[set][j], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s < 2 && (q < 4 || q >= 12)) {
+                        const int c = s * 8 + (q < 4 ? q : q - 8);
+#ifndef ADA_ABL_WR
+                        wr(c, sbn);
+#endif
+#ifndef ADA_ABL_GL
+                        gl(c, aoff, boff);
+#endif
+                    }
+#ifndef ADA_ABL_RD
+                    if (q >= 4 && q < 12) {
+                        if (s < NSUB - 1) rd1(set ^ 1, s + 1, sb, q - 4);
+                        else rd1(set ^ 1, 0, sbn, q - 4);
+                    }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
         // All copies of slab t+1 are issued right after the barrier; fragment reads are scheduled by the compiler.
         // (Hand-counted lgkmcnt pipelines and a ping-pong split of the two waves per SIMD were tried and measured: fewer
         // cycles per k-step but no wall-clock gain on this power-limited kernel -- profiles/r01_c_gemm_sched{4,5}_ab.txt.)
@@ -552,6 +649,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
         }
     }
     if (p.dbg && tid == 0) {
+        const unsigned long long t_issued = __builtin_amdgcn_s_memtime();   // epilogue instructions issued, stores in flight
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long* d = p.dbg + (long)blockIdx.x * 8;
         unsigned hwid;
@@ -559,7 +657,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(IgemmD
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         d[0] = t_entry; d[1] = t_first; d[2] = t_loop; d[3] = __builtin_amdgcn_s_memtime();
-        d[4] = ((unsigned long long)xcc << 32) | hwid; d[5] = ((unsigned long long)tm << 32) | (unsigned)tn;
+        d[4] = ((unsigned long long)xcc << 32) | hwid; d[5] = t_issued;
         d[6] = t_vm; d[7] = t_bar;
     }
 }
@@ -646,6 +744,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
             case 4: return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
             case 5: return launch_cfg<128, 256, 32, 2, 2, EPI>(d, s);
             case 7: return launch_cfg<512, 128, 64, 8, 1, EPI>(d, s);
+            case 8: return launch_cfg<256, 256, 64, 2, 2, EPI>(d, s);
             default: return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
         }
     }

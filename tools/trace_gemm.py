@@ -16,7 +16,7 @@ op = H.operand_dtype()
 lib = H.load()
 lib.ada_debug_set_timestamps.argtypes = [ctypes.c_void_p]
 T = 43840
-cases = {"proj": (T, 1024, 1024, "f32res"), "qkv": (T, 3072, 1024, "op"), "fc2": (T, 1024, 4096, "f32res"), "big": (8192, 8192, 8192, "f32")}
+cases = {"proj_f32": (T, 1024, 1024, "f32"), "proj_op": (T, 1024, 1024, "op"), "few64": (16384, 256, 1024, "op"), "few64res": (16384, 256, 1024, "f32res"), "few256": (16384, 1024, 1024, "op"), "few256res": (16384, 1024, 1024, "f32res"), "proj": (T, 1024, 1024, "f32res"), "qkv": (T, 3072, 1024, "op"), "fc1": (T, 4096, 1024, "gelu"), "fc2": (T, 1024, 4096, "f32res"), "big": (8192, 8192, 8192, "f32")}
 for name in sys.argv[1:] or ["proj"]:
     M, N, K, mode = cases[name]
     A = torch.randn(M, K, device="cuda").to(op)
@@ -25,6 +25,8 @@ for name in sys.argv[1:] or ["proj"]:
     args = dict(M=M, N=N, K=K, A=A, lda=K, W=W, bias=bias, flags=H.EP_BIAS)
     if mode == "op":
         args.update(out_op=torch.empty(M, N, dtype=op, device="cuda"), ldo_op=N)
+    elif mode == "gelu":
+        args.update(out_op=torch.empty(M, N, dtype=op, device="cuda"), ldo_op=N, flags=H.EP_BIAS | H.EP_GELU)
     elif mode == "f32res":
         x = torch.randn(M, N, device="cuda")
         args.update(gamma=torch.rand(N, device="cuda"), res=x, ldr=N, out_f32=x, ldo_f32=N, flags=H.EP_BIAS | H.EP_GAMMA | H.EP_RESIDUAL)
@@ -46,10 +48,27 @@ for name in sys.argv[1:] or ["proj"]:
     hw = d[:, 4] & 0xFFFFFFFF
     cu = (hw >> 8) & 0xF
     se = (hw >> 13) & 0x7  # informational
-    print(f"== {name}: M={M} N={N} K={K}  blocks={nblk}  total span {float(end.max()):.0f} ticks")
+    # s_memtime counters are per XCD: measure the launch span inside each XCD and average
+    key = (d[:, 4] >> 32) * 65536 + (d[:, 4] & 0xFF00)   # (XCC_ID, se/sh/cu of HW_ID): one compute unit
+    spans = []
+    for kv in key.unique():
+        sel = key == kv
+        spans.append(float(d[sel, 3].max() - d[sel, 0].min()))
+    spans.sort()
+    spans = spans[len(spans) // 4: -(len(spans) // 4) or None]   # inter-quartile: counters of different CUs are not comparable
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        H.igemm(**args)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 5 * 1e3
+    span = sum(spans) / len(spans)
+    print(f"== {name}: M={M} N={N} K={K}  blocks={nblk}  span {span:.0f} ticks per CU, {us:.1f} us per launch -> shader clock ~{span / us / 1e3:.2f} GHz")
     print(f"   prologue (entry->first slab): mean {float((first - ent).mean()):8.0f}  max {float((first - ent).max()):8.0f}")
     print(f"   main loop                  : mean {float((loop - first).mean()):8.0f}  min {float((loop - first).min()):8.0f} max {float((loop - first).max()):8.0f}  per k-step {float((loop - first).mean()) / (K // 64 - 0):.0f}")
     print(f"   epilogue                   : mean {float((end - loop).mean()):8.0f}  min {float((end - loop).min()):8.0f} max {float((end - loop).max()):8.0f}")
+    print(f"   epilogue issue / store drain: mean {float((d[:, 5] - d[:, 2]).double().mean()):8.0f} / {float((d[:, 3] - d[:, 5]).double().mean()):8.0f}")
     print(f"   wave0 waits in main loop   : vmcnt mean {float(d[:, 6].double().mean()):8.0f}  barrier mean {float(d[:, 7].double().mean()):8.0f}  (per k-step {float(d[:, 6].double().mean()) / (K // 64):.0f} / {float(d[:, 7].double().mean()) / (K // 64):.0f})")
     order = torch.argsort(ent)
     # round structure: entry time histogram

@@ -16,7 +16,7 @@ op = H.operand_dtype()
 lib = H.load()
 lib.ada_debug_set_timestamps.argtypes = [ctypes.c_void_p]
 T = 43840
-cases = {"proj_f32": (T, 1024, 1024, "f32"), "proj_op": (T, 1024, 1024, "op"), "few64": (16384, 256, 1024, "op"), "few64res": (16384, 256, 1024, "f32res"), "few256": (16384, 1024, 1024, "op"), "few256res": (16384, 1024, 1024, "f32res"), "proj": (T, 1024, 1024, "f32res"), "qkv": (T, 3072, 1024, "op"), "fc1": (T, 4096, 1024, "gelu"), "fc2": (T, 1024, 4096, "f32res"), "big": (8192, 8192, 8192, "f32")}
+cases = {"fc1_op": (T, 4096, 1024, "op"), "fc1_op_pad": (T, 4096, 1024, "op_pad"), "fc1_pad": (T, 4096, 1024, "gelu_pad"), "qkv_pad": (T, 3072, 1024, "op_pad"), "proj_f32": (T, 1024, 1024, "f32"), "proj_op": (T, 1024, 1024, "op"), "few64": (16384, 256, 1024, "op"), "few64res": (16384, 256, 1024, "f32res"), "few256": (16384, 1024, 1024, "op"), "few256res": (16384, 1024, 1024, "f32res"), "proj": (T, 1024, 1024, "f32res"), "qkv": (T, 3072, 1024, "op"), "fc1": (T, 4096, 1024, "gelu"), "fc2": (T, 1024, 4096, "f32res"), "big": (8192, 8192, 8192, "f32")}
 for name in sys.argv[1:] or ["proj"]:
     M, N, K, mode = cases[name]
     A = torch.randn(M, K, device="cuda").to(op)
@@ -25,6 +25,8 @@ for name in sys.argv[1:] or ["proj"]:
     args = dict(M=M, N=N, K=K, A=A, lda=K, W=W, bias=bias, flags=H.EP_BIAS)
     if mode == "op":
         args.update(out_op=torch.empty(M, N, dtype=op, device="cuda"), ldo_op=N)
+    elif mode in ("op_pad", "gelu_pad"):
+        args.update(out_op=torch.empty(M, N + 64, dtype=op, device="cuda"), ldo_op=N + 64, flags=H.EP_BIAS | (H.EP_GELU if mode == "gelu_pad" else 0))
     elif mode == "gelu":
         args.update(out_op=torch.empty(M, N, dtype=op, device="cuda"), ldo_op=N, flags=H.EP_BIAS | H.EP_GELU)
     elif mode == "f32res":
@@ -69,6 +71,8 @@ for name in sys.argv[1:] or ["proj"]:
     print(f"   main loop                  : mean {float((loop - first).mean()):8.0f}  min {float((loop - first).min()):8.0f} max {float((loop - first).max()):8.0f}  per k-step {float((loop - first).mean()) / (K // 64 - 0):.0f}")
     print(f"   epilogue                   : mean {float((end - loop).mean()):8.0f}  min {float((end - loop).min()):8.0f} max {float((end - loop).max()):8.0f}")
     print(f"   epilogue issue / store drain: mean {float((d[:, 5] - d[:, 2]).double().mean()):8.0f} / {float((d[:, 3] - d[:, 5]).double().mean()):8.0f}")
+    if mode in ("f32res", "f32"):
+        print(f"   f32 epilogue phases (overwrite the main-loop wait slots): dump->LDS landed {float(d[:, 6].double().mean()):8.0f}   vmcnt(0) wait {float(d[:, 7].double().mean()):8.0f}")
     print(f"   wave0 waits in main loop   : vmcnt mean {float(d[:, 6].double().mean()):8.0f}  barrier mean {float(d[:, 7].double().mean()):8.0f}  (per k-step {float(d[:, 6].double().mean()) / (K // 64):.0f} / {float(d[:, 7].double().mean()) / (K // 64):.0f})")
     order = torch.argsort(ent)
     # round structure: entry time histogram

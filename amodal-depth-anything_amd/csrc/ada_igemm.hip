@@ -89,6 +89,35 @@ ADA_DEV long map_row(const IgemmDev& p, int map, uint32_t m) {
     return ((long)b * (p.map_h + 2) + (y + 1)) * (p.map_w + 2) + (x + 1);
 }
 
+// Walks GEMM rows m, m+step, m+2*step ... through the interior of a zero-bordered [B, map_h+2, map_w+2] grid without a
+// division per row (valid for step <= map_w).
+struct PadWalk {
+    int x, y;
+    long prow;
+};
+ADA_DEV PadWalk pad_start(const IgemmDev& p, uint32_t m) {
+    uint32_t b, rem, y, x;
+    fast_divmod(m, p.dMapHW, b, rem);
+    fast_divmod(rem, p.dMapW, y, x);
+    PadWalk w;
+    w.x = (int)x; w.y = (int)y;
+    w.prow = ((long)b * (p.map_h + 2) + (y + 1)) * (p.map_w + 2) + (x + 1);
+    return w;
+}
+ADA_DEV void pad_step(const IgemmDev& p, PadWalk& w, int step) {
+    w.x += step;
+    w.prow += step;
+    if (w.x >= p.map_w) {
+        w.x -= p.map_w;
+        w.y += 1;
+        w.prow += 2;
+        if (w.y >= p.map_h) {
+            w.y = 0;
+            w.prow += 2 * (p.map_w + 2);
+        }
+    }
+}
+
 ADA_DEV opx4 pack4(float4 v) {
     opx4 o;
     o[0] = to_op(v.x); o[1] = to_op(v.y); o[2] = to_op(v.z); o[3] = to_op(v.w);
@@ -462,10 +491,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             }
         }
     } else if (EPI != EPI_SHUFFLE && m0 + BM <= p.M && n0 + BN <= p.N && p.res_row_mod == 0 &&
-               (!p.out_op || p.map_op == ADA_MAP_PLAIN) && (!p.out_f32 || p.map_f32 == ADA_MAP_PLAIN) &&
+               (!p.out_op || p.map_op == ADA_MAP_PLAIN || (p.map_op == ADA_MAP_PAD && p.map_w >= 8)) &&
+               (!p.out_f32 || p.map_f32 == ADA_MAP_PLAIN) &&
                (p.out_f32 || (flags & ADA_EP_RESIDUAL) || (p.ldo_op & 7) == 0)) {
-        // ---- interior tiles with plain row maps (every linear layer of the encoder): no bounds checks, no row mapping, row
-        //      pointers advance by constant strides.  The general code below spends most of its issue slots on exactly that
+        // ---- interior tiles with plain (or zero-bordered NHWC) row maps -- every linear layer of the encoder, the 3x3 convs of
+        //      the head: no bounds checks, no per-row division, row pointers advance by constant strides / a PadWalk.  The general code below spends most of its issue slots on exactly that
         //      bookkeeping: 10.7 k cycles per 256x256 tile for fp16 output, 35 k for the fp32 residual update, against 4-8 k
         //      for this path (profiles/r01_g_gemm_tile_anatomy.txt) -- the epilogue is VALU-issue-bound, not memory-bound.
         const bool has_bias = (flags & ADA_EP_BIAS) != 0, has_gamma = (flags & ADA_EP_GAMMA) != 0;
@@ -481,9 +511,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 if (has_bias) { b0 = *(const float4*)(p.bias + n); b1 = *(const float4*)(p.bias + n + 4); }
                 if (has_gamma) { g0 = *(const float4*)(p.gamma + n); g1 = *(const float4*)(p.gamma + n + 4); }
                 op_t* dst = p.out_op + (long)(mbase + rsub) * ld + n;
+                const bool pad = p.map_op == ADA_MAP_PAD;
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
                     dump(i, g);
+                    PadWalk walk;
+                    if (pad) walk = pad_start(p, (uint32_t)(mbase + i * 32 + rsub));
 #pragma unroll
                     for (int k = 0; k < 32 / RPI; ++k) {
                         const int row = k * RPI + rsub;
@@ -507,7 +540,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                         opx8 o;
                         o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
                         o[4] = hi4[0]; o[5] = hi4[1]; o[6] = hi4[2]; o[7] = hi4[3];
-                        *(opx8*)(dst + (long)(i * 32 + k * RPI) * ld) = o;
+                        if (pad) {
+                            *(opx8*)(p.out_op + walk.prow * ld + n) = o;
+                            pad_step(p, walk, RPI);
+                        } else {
+                            *(opx8*)(dst + (long)(i * 32 + k * RPI) * ld) = o;
+                        }
                     }
                 }
             }
@@ -554,6 +592,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 }
                 dump(i, g);
                 const long mrow = mbase + i * 32 + rsub;
+                const bool pad = p.out_op && p.map_op == ADA_MAP_PAD;
+                PadWalk walk;
+                if (pad) walk = pad_start(p, (uint32_t)mrow);
 #pragma unroll
                 for (int k = 0; k < NKI; ++k) {
                     float4 v = *(const float4*)(slab + (k * RPI + rsub) * GW + 4 * cg);
@@ -576,7 +617,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                             v.x = __builtin_fmaxf(v.x, 0.f); v.y = __builtin_fmaxf(v.y, 0.f);
                             v.z = __builtin_fmaxf(v.z, 0.f); v.w = __builtin_fmaxf(v.w, 0.f);
                         }
-                        *(opx4*)(p.out_op + (mrow + k * RPI) * ldo + n) = pack4(v);
+                        if (pad) {
+                            *(opx4*)(p.out_op + walk.prow * ldo + n) = pack4(v);
+                            pad_step(p, walk, RPI);
+                        } else {
+                            *(opx4*)(p.out_op + (mrow + k * RPI) * ldo + n) = pack4(v);
+                        }
                     }
                 }
                 if constexpr (AHEAD) {

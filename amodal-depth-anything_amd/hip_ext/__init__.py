@@ -28,8 +28,13 @@ ACT_NONE, ACT_SIGMOID, ACT_RELU = 0, 1, 2
 EXPORTS = (
     "ada_abi_version", "ada_operand_dtype", "ada_last_error", "ada_igemm", "ada_attention_fwd",
     "ada_layernorm_fwd", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
-    "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd",
+    "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd",
 )
+
+# indices into the per-image sums of ada_depth_eval_fwd (ADA_EVAL_* in include/ada_hip.h)
+EVAL_N, EVAL_SUM_P, EVAL_SUM_G, EVAL_SUM_PP, EVAL_SUM_PG, EVAL_ABS_REL, EVAL_SQ_REL, EVAL_SQ, EVAL_LOG_SQ, EVAL_LOG, \
+    EVAL_LOG10_ABS, EVAL_D1, EVAL_D2, EVAL_D3, EVAL_INV_SQ = range(15)
+EVAL_NSUM = 16
 
 
 class IgemmArgs(ctypes.Structure):
@@ -102,6 +107,8 @@ def load(path: Optional[str] = None):
     lib.ada_normalize_fwd.restype = c_int
     lib.ada_blend_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
     lib.ada_blend_fwd.restype = c_int
+    lib.ada_depth_eval_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_float, c_float, c_void_p, c_void_p]
+    lib.ada_depth_eval_fwd.restype = c_int
     if lib.ada_abi_version() != ABI_VERSION:
         raise HipExtError(f"{path}: ABI version {lib.ada_abi_version()} != binding version {ABI_VERSION}")
     _lib, _lib_path = lib, path
@@ -257,6 +264,24 @@ def blend(amodal, base, mask, out):
     B, H, W = amodal.shape[0], amodal.shape[-2], amodal.shape[-1]
     _check(load().ada_blend_fwd(_dev(amodal, "amodal", torch.float32), _dev(base, "base", torch.float32), _dev(mask, "mask", torch.float32),
                                 B, H, W, _dev(out, "out", torch.float32), _stream()), "ada_blend_fwd")
+
+
+def depth_eval(pred, gt, mask=None, scale_shift=None, clip=None) -> torch.Tensor:
+    """Per-image masked evaluation sums, fp64 [B, EVAL_NSUM] (ada_depth_eval_fwd).  pred / gt: fp32 [B, ...]; mask: uint8/bool
+    of the same shape or None; scale_shift: fp32 [B, 2] or None; clip: (lo, hi) or None."""
+    B = pred.shape[0]
+    n = pred[0].numel()
+    if gt.shape != pred.shape or (mask is not None and mask.shape != pred.shape):
+        raise HipExtError(f"depth_eval: shape mismatch pred {tuple(pred.shape)} gt {tuple(gt.shape)}")
+    if mask is not None and mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8) if mask.is_contiguous() else mask.to(torch.uint8)
+    sums = torch.empty(B, EVAL_NSUM, dtype=torch.float64, device=pred.device)
+    lo, hi = (float(clip[0]), float(clip[1])) if clip is not None else (0.0, 0.0)
+    _check(load().ada_depth_eval_fwd(_dev(pred, "pred", torch.float32), _dev(gt, "gt", torch.float32),
+                                     _dev(mask, "mask", torch.uint8) if mask is not None else None, B, n,
+                                     _dev(scale_shift, "scale_shift", torch.float32) if scale_shift is not None else None,
+                                     lo, hi, _dev(sums, "sums", torch.float64), _stream()), "ada_depth_eval_fwd")
+    return sums
 
 
 def selftest() -> int:

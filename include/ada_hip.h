@@ -189,6 +189,37 @@ int ada_bilinear_fwd(const float* in, int64_t ld_in, int32_t batch, int32_t hi, 
                      int32_t relu, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Depth evaluation sums.  Replaces the host-side numpy/torch evaluation of the reference:
+ * the masked reductions behind src/util/metric.py:37-160 (abs_relative_difference, squared_relative_difference,
+ * rmse_linear, rmse_log, log10, threshold_percentage = delta1/2/3, i_rmse, silog_rmse) and the normal-equation sums of
+ * align_depth_least_square (src/util/alignment.py:7-54), all from ONE pass over the maps.
+ *   pred, gt   fp32 [B, n_per_image];  mask uint8 [B, n_per_image] (non-zero = valid) or NULL (all valid)
+ *   scale_shift fp32 [B, 2] or NULL: p = pred * scale + shift is what gets evaluated (the aligned prediction);
+ *               clip_lo < clip_hi additionally clamps p to [clip_lo, clip_hi] (dataset depth range)
+ *   sums       fp64 [B, ADA_EVAL_NSUM] (overwritten), indexed by the ADA_EVAL_* constants; p, gt must be > 0 where valid
+ *               for the log / ratio / inverse terms to be meaningful (as in the reference)
+ * ---------------------------------------------------------------------------------------- */
+#define ADA_EVAL_N 0          /* valid pixels */
+#define ADA_EVAL_SUM_P 1      /* sum p */
+#define ADA_EVAL_SUM_G 2      /* sum gt */
+#define ADA_EVAL_SUM_PP 3     /* sum p*p */
+#define ADA_EVAL_SUM_PG 4     /* sum p*gt */
+#define ADA_EVAL_ABS_REL 5    /* sum |p-gt|/gt */
+#define ADA_EVAL_SQ_REL 6     /* sum (p-gt)^2/gt */
+#define ADA_EVAL_SQ 7         /* sum (p-gt)^2 */
+#define ADA_EVAL_LOG_SQ 8     /* sum (ln p - ln gt)^2 */
+#define ADA_EVAL_LOG 9        /* sum (ln p - ln gt) */
+#define ADA_EVAL_LOG10_ABS 10 /* sum |log10 p - log10 gt| */
+#define ADA_EVAL_D1 11        /* #{max(p/gt, gt/p) < 1.25} */
+#define ADA_EVAL_D2 12        /* ... < 1.25^2 */
+#define ADA_EVAL_D3 13        /* ... < 1.25^3 */
+#define ADA_EVAL_INV_SQ 14    /* sum (1/p - 1/gt)^2 */
+#define ADA_EVAL_NSUM 16
+int ada_depth_eval_fwd(const float* pred, const float* gt, const uint8_t* mask, int32_t batch,
+                       int64_t n_per_image, const float* scale_shift, float clip_lo, float clip_hi,
+                       double* sums, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Device-side glue of the two-model pipeline of infer.py (kept in HBM instead of bouncing through numpy):
  *   ada_minmax_fwd     per-image min / max of a [B, n] fp32 map -> minmax[B, 2]          (infer.py:22)
  *   ada_normalize_fwd  norm = (d - min) / (max - min) and/or obs = norm * 2 - 1          (infer.py:22,92)

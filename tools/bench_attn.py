@@ -17,6 +17,8 @@ torch.manual_seed(0)
 qkv = torch.randn(B * N, 3 * D, device="cuda")
 qkv[:, :D] *= 0.125 * 1.4426950408889634
 qkv = qkv.to(op)
+if os.environ.get("ZERO"):
+    qkv.zero_()
 out = torch.empty(B * N, D, dtype=op, device="cuda")
 reps = int(os.environ.get("REPS", 10))
 for _ in range(2):

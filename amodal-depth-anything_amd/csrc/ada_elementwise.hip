@@ -221,6 +221,81 @@ __global__ __launch_bounds__(256) void bilinear_kernel(BilinearArgs p) {
     }
 }
 
+// LDS-tiled variant for up-sampling wide-channel maps (the DPT fusion path: 128 / 256 channels).  One workgroup produces an
+// 8 x 32 tile of output pixels for a chunk of 128 channels.  The source patch the tile touches (at most 6 x 20 pixels at the
+// scales used here) is copied ONCE into LDS by global_load_lds (16 B per lane, lane-linear: pixel-major, 512 B per pixel), then
+// every output reads its four taps from LDS.  The per-pixel kernel above re-fetches each source pixel ~12x through L2 (the
+// workgroups sharing a source row run on different CUs) and tops out near 3 TB/s; this one reads the source about once.
+constexpr int BT_TH = 8, BT_TW = 32, BT_CG = 32;   // tile height / width in output pixels, float4 channel groups per chunk
+
+__global__ __launch_bounds__(256) void bilinear_tiled_kernel(BilinearArgs p, int ph, int pw, int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) char bl_smem[];
+    const int tid = threadIdx.x;
+    const int g = tid & (BT_CG - 1), psub = tid >> 5;     // channel group, pixel slot (8 pixels per pass)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z / nchunk, chunk = blockIdx.z - b * nchunk;
+    const int c0 = chunk * BT_CG;                           // first float4 channel group of this chunk
+    const int tx0 = blockIdx.x * BT_TW, ty0 = blockIdx.y * BT_TH;
+    const int py0 = (int)(p.sy * (float)ty0), px0 = (int)(p.sx * (float)tx0);   // top-left source pixel of the patch
+    // ---- stage the patch: pass i copies patch pixels 8i .. 8i+7 (clamped to the image), 32 channel groups each ----------
+    const int npix = ph * pw;
+    const long img = (long)b * p.hi;
+    for (int base = 0; base < npix; base += 8) {
+        int pp = base + psub;
+        if (pp >= npix) pp = npix - 1;
+        const int r = pp / pw, c = pp - r * pw;
+        int yy = py0 + r, xx = px0 + c;
+        if (yy > p.hi - 1) yy = p.hi - 1;
+        if (xx > p.wi - 1) xx = p.wi - 1;
+        const float* src = p.in + ((img + yy) * p.wi + xx) * p.ld_in + 4 * (c0 + g);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(bl_smem + base * 512 + wave * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- 256 output pixels, 8 per pass --------------------------------------------------------------------------
+#pragma unroll 4
+    for (int it = 0; it < BT_TH * BT_TW / 8; ++it) {
+        const int py = it >> 2, px = ((it & 3) << 3) + psub;
+        const int y = ty0 + py, x = tx0 + px;
+        if (y >= p.ho || x >= p.wo) continue;
+        const float fy = p.sy * (float)y, fx = p.sx * (float)x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < p.hi - 1 ? 1 : 0), x1 = x0 + (x0 < p.wi - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
+        const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+        const char* t0 = bl_smem + ((y0 - py0) * pw - px0) * 512 + g * 16;
+        const char* t1 = bl_smem + ((y1 - py0) * pw - px0) * 512 + g * 16;
+        const float4 v00 = *(const float4*)(t0 + x0 * 512);
+        const float4 v01 = *(const float4*)(t0 + x1 * 512);
+        const float4 v10 = *(const float4*)(t1 + x0 * 512);
+        const float4 v11 = *(const float4*)(t1 + x1 * 512);
+        float4 r;
+        r.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+        r.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+        r.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+        r.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+        const int c = c0 + g;
+        const long pix = ((long)b * p.ho + y) * p.wo + x;
+        if (p.add) {
+            const float4 a = ((const float4*)(p.add + pix * p.ld_add))[c];
+            r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
+        }
+        if (p.out_f32) ((float4*)(p.out_f32 + pix * p.ld_f32))[c] = r;
+        if (p.out_op) {
+            long orow = pix;
+            if (p.map_op == ADA_MAP_PAD) orow = ((long)b * (p.ho + 2) + (y + 1)) * (p.wo + 2) + (x + 1);
+            if (p.relu) {
+                r.x = __builtin_fmaxf(r.x, 0.f); r.y = __builtin_fmaxf(r.y, 0.f);
+                r.z = __builtin_fmaxf(r.z, 0.f); r.w = __builtin_fmaxf(r.w, 0.f);
+            }
+            opx4 o;
+            o[0] = to_op(r.x); o[1] = to_op(r.y); o[2] = to_op(r.z); o[3] = to_op(r.w);
+            ((opx4*)(p.out_op + orow * p.ld_op))[c] = o;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ada_layernorm_fwd(const float* in, int64_t ld_in, int32_t rows_out, int32_t dim, int32_t group_in, int32_t skip,
@@ -293,6 +368,34 @@ extern "C" int ada_bilinear_fwd(const float* in, int64_t ld_in, int32_t batch, i
     p.map_op = map_op; p.relu = relu;
     p.dC4 = make_fastdiv(p.c4); p.dWo = make_fastdiv(wo); p.dHo = make_fastdiv(ho);
     ADA_REQUIRE(ho <= 65535 && batch <= 65535, ADA_EUNSUPPORTED, "ada_bilinear_fwd: ho / batch exceed the grid limits");
+    // LDS-tiled path: up-sampling, channels in chunks of 128, source patch of an 8 x 32 output tile within 64 KiB
+    // exact patch extent: the same fp32 expressions the kernel evaluates, maximised over the tile rows / columns
+    auto extent = [](float sc, int n_in, int n_out, int tile) {
+        int best = 1;
+        for (int t0 = 0; t0 < n_out; t0 += tile) {
+            const int last = t0 + tile - 1 < n_out - 1 ? t0 + tile - 1 : n_out - 1;
+            int hi_tap = (int)(sc * (float)last) + 1;
+            if (hi_tap > n_in - 1) hi_tap = n_in - 1;
+            const int e = hi_tap - (int)(sc * (float)t0) + 1;
+            if (e > best) best = e;
+        }
+        return best;
+    };
+    const int ph = extent(p.sy, hi, ho, BT_TH), pw = extent(p.sx, wi, wo, BT_TW);
+    const int nchunk = channels / (4 * BT_CG);
+    const bool tiled = channels % (4 * BT_CG) == 0 && p.sy <= 1.0f && p.sx <= 1.0f && ho >= BT_TH && wo >= BT_TW && ph * pw * 512 <= 65536 &&
+                       (long)batch * nchunk <= 65535 && !getenv("ADA_BILINEAR_SIMPLE");
+    if (tiled) {
+        const int smem = ((ph * pw + 7) / 8) * 8 * 512;
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute((const void*)bilinear_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) (void)hipGetLastError();
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(bilinear_tiled_kernel, dim3((unsigned)((wo + BT_TW - 1) / BT_TW), (unsigned)((ho + BT_TH - 1) / BT_TH), (unsigned)(batch * nchunk)),
+                           dim3(256), smem, (hipStream_t)stream, p, ph, pw, nchunk);
+        return ada_check_launch("ada_bilinear_fwd");
+    }
     hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)((wo * p.c4 + 255) / 256), (unsigned)ho, (unsigned)batch), dim3(256), 0,
                        (hipStream_t)stream, p);
     return ada_check_launch("ada_bilinear_fwd");

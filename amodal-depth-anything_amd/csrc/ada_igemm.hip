@@ -835,6 +835,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
 }
 
 static int g_group_override = 0;  // debug: force the column-group width (0 = model)
+static int g_long_k_cfg = 3;       // tile for K > 2048 (A/B switch ADA_IGEMM_LONGK: 3 = 8 waves, 8 = 4-wave pipelined)
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
 int launch_cfg(IgemmDev& d, hipStream_t stream) {
@@ -892,7 +893,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
     else {
         // large problems: the 256x256 tile (best MFMA efficiency); small ones (single images, ViT-S/B at small batch)
         // would leave most CUs idle with it, so pick the tile that minimises the quantised time estimate
-        cfg = (d.K <= 2048) ? short_k_cfg : 3;
+        cfg = (d.K <= 2048) ? short_k_cfg : g_long_k_cfg;
         double best = tile_time(d.M, d.N, 256, 256, 1, 1.0);
         const double t2 = tile_time(d.M, d.N, 256, 128, 1, 0.90), t4 = tile_time(d.M, d.N, 128, 128, 2, 0.85),
                      t1 = tile_time(d.M, d.N, 128, 64, 3, 0.65);
@@ -1027,6 +1028,8 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
         if (va) g_variant = atoi(va);
         const char* sk = getenv("ADA_IGEMM_SHORTK");
         g_short_k_cfg = sk ? atoi(sk) : 3;
+        const char* lk = getenv("ADA_IGEMM_LONGK");
+        if (lk) g_long_k_cfg = atoi(lk);
     }
     const int force = g_force_tile, short_k_cfg = g_short_k_cfg;
     d.dbg = g_dbg;

@@ -290,6 +290,56 @@ def test_bilinear_align_corners(hip, hi, wi, ho, wo):
     _close(oo[:, 1:-1, 1:-1].reshape(-1, C), ref.clamp_min(0), 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="bilinear op")
 
 
+@pytest.mark.parametrize("C,hi,wi,ho,wo", [(128, 19, 19, 37, 37), (256, 37, 37, 74, 74), (128, 20, 30, 35, 49), (256, 30, 41, 60, 82), (128, 74, 74, 129, 129)])
+@pytest.mark.parametrize("mode", ["all", "f32_only", "op_plain"])
+def test_bilinear_tiled_wide_channels(hip, C, hi, wi, ho, wo, mode):
+    """128 / 256 channels take the LDS-tiled kernel (8x32 output tiles, source patch staged once): partial tiles at the right and
+    bottom edges, non-square maps, a non-integer scale, every output combination."""
+    op = _op(hip)
+    B = 2
+    x = _rand(B, C, hi, wi, seed=146)
+    xin = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV)
+    ref = F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).reshape(-1, C)
+    if mode == "all":
+        add = _rand(B * ho * wo, C, seed=147)
+        of = torch.zeros(B * ho * wo, C, device=DEV)
+        oo = torch.zeros(B, ho + 2, wo + 2, C, dtype=op, device=DEV)
+        hip.bilinear(xin, C, B, hi, wi, ho, wo, C, add=add.to(DEV), ld_add=C, out_f32=of, ld_f32=C, out_op=oo, ld_op=C, map_op=hip.MAP_PAD, relu=True)
+        ref = ref + add
+        _close(of, ref, 2e-5, rtol=1e-5, what="tiled bilinear f32")
+        _close(oo[:, 1:-1, 1:-1].reshape(-1, C), ref.clamp_min(0), 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="tiled bilinear op")
+        border = oo.clone()
+        border[:, 1:-1, 1:-1] = 0
+        assert float(border.abs().max()) == 0.0
+    elif mode == "f32_only":
+        of = torch.zeros(B * ho * wo, C, device=DEV)
+        hip.bilinear(xin, C, B, hi, wi, ho, wo, C, out_f32=of, ld_f32=C)
+        _close(of, ref, 2e-5, rtol=1e-5, what="tiled bilinear f32 only")
+    else:
+        oo = torch.zeros(B * ho * wo, C, dtype=op, device=DEV)
+        hip.bilinear(xin, C, B, hi, wi, ho, wo, C, out_op=oo, ld_op=C, map_op=hip.MAP_PLAIN)
+        _close(oo, ref, 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="tiled bilinear op plain")
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 40, 23), (3, 128, 9, 5), (1, 256, 33, 70)])
+def test_igemm_conv3x3_padded_output_interior_and_edge_tiles(hip, B, C, H, W):
+    """Zero-bordered NHWC output over tiles that are fully interior (streamlined epilogue, row walk without divisions), tiles that
+    cross image boundaries, the ragged last tile, and a grid narrower than the walk step (general path)."""
+    op = _op(hip)
+    x = _rand(B, C, H, W, seed=119).to(op).float()
+    w = (_rand(C, C, 3, 3, seed=120) * (9 * C) ** -0.5).to(op).float()
+    b = _rand(C, seed=121)
+    out_p = torch.zeros(B, H + 2, W + 2, C, dtype=op, device=DEV)
+    hip.igemm(M=B * H * W, N=C, K=9 * C, A=_pad_nhwc(x, C, op).to(DEV), lda=C, W=_pack3(w, C, op).to(DEV), a_mode=hip.A_CONV3,
+              conv=(H, W, H + 2, W + 2, 1), bias=b.to(DEV), flags=hip.EP_BIAS | hip.EP_RELU_OP,
+              out_op=out_p, ldo_op=C, map_op=hip.MAP_PAD, map_h=H, map_w=W)
+    ref = F.conv2d(x, w, b, padding=1).clamp_min(0).permute(0, 2, 3, 1).reshape(-1, C)
+    _close(out_p[:, 1:-1, 1:-1].reshape(-1, C), ref, 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="conv relu padded")
+    border = out_p.clone()
+    border[:, 1:-1, 1:-1] = 0
+    assert float(border.abs().max()) == 0.0
+
+
 def test_errors_are_reported_not_thrown(hip):
     op = _op(hip)
     A = torch.zeros(64, 64, dtype=op, device=DEV)

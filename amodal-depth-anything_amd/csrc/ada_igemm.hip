@@ -148,8 +148,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31;
-    const int hi = lane >> 5;
 
     // XCD-aware (bijective) block remap: each XCD's L2 sees a contiguous run of tiles that share A panels.
     int tm, tn;
@@ -238,17 +236,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
 
     // ---- main loop -----------------------------------------------------------------------
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    f32x16 acc[TI][TJ];
+    // v_mfma_f32_16x16x32: four 16x16 sub-tiles per 32x32 block (index 2a+b = row half a, column half b).  Same FLOPs per
+    // LDS byte as the 32x32x16 instruction but a better rate under the power cap: +7-9 % on every GEMM shape of the model
+    // (profiles/r01_j_gemm_mfma16_ab.txt; registers-only streams: 1.79 vs 1.72 PF, profiles/r01_g_mfma_power_ceiling.txt).
+    f32x4 acc[TI][TJ][4];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int swz = (CHUNKS == 8) ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
-    const int a_row_off = (wm * TI * 32 + l31) * RB;
-    const int b_row_off = A_BYTES + (wn * TJ * 32 + l31) * RB;
+            for (int ab = 0; ab < 4; ++ab)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][ab][r] = 0.0f;
 
     const int nk = p.K / BK;
     {
@@ -256,104 +255,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
         slab_offsets(0, aoff, boff);
         stage_part(0, aoff, boff, -1);
     }
-    // One wave per SIMD (4 waves, 128x128 wave tile, 256 accumulator registers in AGPRs): nobody else hides this wave's
-    // latencies, so the loop is software-pipelined by hand, three slabs deep:
-    //   slab kt    : in LDS stage kt&1, fragments double-buffered in registers (ds_reads of sub-step s+1 under the MFMAs of s)
-    //   slab kt+1  : in 16 staging registers per lane at the top of the k-step, written to the other LDS stage during
-    //                sub-steps 0-1 (ds_write_b128, lane-linear = the same swizzled layout the LDS-DMA path produces)
-    //   slab kt+2  : global_load_dwordx4 into each staging register right after it has been written out (a full k-step to land)
-    // Every filler instruction is slotted between two MFMAs (each holds the matrix pipe 32 cycles; <= 4 fillers per gap).
-    // LDS-DMA (global_load_lds) is not used here: with one wave per SIMD its m0 set-up and issue cost (~60 cycles each,
-    // 16 per k-step) is exposed -- measured 45 cycles per MFMA slot against 33-35 with register staging.
-    // The workgroup barrier sits before the last sub-step's MFMAs: by then every wave has written its part of slab kt+1 and
-    // holds its last fragments of slab kt in registers, so the first fragments of kt+1 are fetched under the last 16 MFMAs.
-    constexpr bool PIPE = (NWAVES == 4 && TI == 4 && TJ == 4 && BK == 64);
-    if constexpr (PIPE) {
-        static_assert(A_IT == 8 && B_IT == 8, "16 staging registers, 8 written per sub-step in sub-steps 0 and 1");
-        const unsigned lds0 = (unsigned)(size_t)smem;
-        unsigned aofs[NSUB], bofs[NSUB];
-#pragma unroll
-        for (int s = 0; s < NSUB; ++s) {
-            const int coff = ((2 * s + hi) ^ swz) * 16;
-            aofs[s] = lds0 + a_row_off + coff;
-            bofs[s] = lds0 + b_row_off + coff;
-        }
-        opx8 fa[2][TI], fb[2][TJ];
-        // fragment read #r (0..7: a0 b0 a1 b1 ...) of sub-step s from the stage at byte offset sb, into register set `set`
-        auto rd1 = [&](int set, int s, unsigned sb, int r) {
-            const int t = r >> 1;
-            if (r & 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[set][t]) : "v"(bofs[s] + sb), "i"(t * 32 * RB));
-            else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[set][t]) : "v"(aofs[s] + sb), "i"(t * 32 * RB));
-        };
-        u32x4 g[A_IT + B_IT];
-        const unsigned wofs = lds0 + tid * 16;
-        auto gl = [&](int c, long aoff, long boff) {   // staging register c <- its 16 bytes of a slab
-            g[c] = c < A_IT ? *(const u32x4*)(a_ptr[c] + aoff) : *(const u32x4*)(b_ptr[c - A_IT] + boff);
-        };
-        auto wr = [&](int c, unsigned sb) {            // staging register c -> LDS stage at byte offset sb
-            if (c < A_IT) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(wofs + sb), "v"(g[c]), "i"(c * (NT * 16)));
-            else asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(wofs + sb), "v"(g[c]), "i"(A_BYTES + (c - A_IT) * (NT * 16)));
-        };
-        {
-            long aoff, boff;
-            slab_offsets(0, aoff, boff);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) gl(c, aoff, boff);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) wr(c, 0u);
-            slab_offsets(nk > 1 ? 1 : 0, aoff, boff);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) gl(c, aoff, boff);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (p.dbg) t_first = __builtin_amdgcn_s_memtime();
-#pragma unroll
-        for (int r = 0; r < 8; ++r) rd1(0, 0, 0u, r);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            long aoff, boff;
-            slab_offsets(kt + 2 < nk ? kt + 2 : nk - 1, aoff, boff);   // past the end: re-load the last slab (never consumed)
-            const unsigned sb = (unsigned)(cur * STAGE_BYTES), sbn = (unsigned)((cur ^ 1) * STAGE_BYTES);
-#pragma unroll
-            for (int s = 0; s < NSUB; ++s) {
-                const int set = s & 1;
-                // fragments of this sub-step have landed; the 4 ds_writes slotted after them may still be in flight
-                if (s == 1 || s == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (s == NSUB - 1) {
-                    unsigned long long tw0 = 0;
-                    if (p.dbg) tw0 = __builtin_amdgcn_s_memtime();
-                    __syncthreads();   // slab kt+1 is complete in LDS, stage `cur` is drained
-                    if (p.dbg) t_bar += __builtin_amdgcn_s_memtime() - tw0;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int i = q >> 2, j = q & 3;
-                    acc[i][j] = mfma32(fa[set][i], fb[set][j], acc[i][j]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (s < 2 && (q < 4 || q >= 12)) {
-                        const int c = s * 8 + (q < 4 ? q : q - 8);
-#ifndef ADA_ABL_WR
-                        wr(c, sbn);
-#endif
-#ifndef ADA_ABL_GL
-                        gl(c, aoff, boff);
-#endif
-                    }
-#ifndef ADA_ABL_RD
-                    if (q >= 4 && q < 12) {
-                        if (s < NSUB - 1) rd1(set ^ 1, s + 1, sb, q - 4);
-                        else rd1(set ^ 1, 0, sbn, q - 4);
-                    }
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    } else {
+    {
         // All copies of slab t+1 are issued right after the barrier; fragment reads are scheduled by the compiler.
         // (Hand-counted lgkmcnt pipelines and a ping-pong split of the two waves per SIMD were tried and measured: fewer
         // cycles per k-step but no wall-clock gain on this power-limited kernel -- profiles/r01_c_gemm_sched{4,5}_ab.txt.)
@@ -373,27 +275,36 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             // The two waves that share a SIMD (w and w+4 of an 8-wave workgroup) leave the barrier together; if both issued
             // their global->LDS copies first, neither would have MFMAs in flight for ~500 cycles.  Variant 1 (default, +3 %
             // measured: profiles/r01_e_gemm_stagger_ab.txt) staggers them: waves 0-3 copy before their MFMAs, waves 4-7
-            // half-way through (their copies still have half a k-step to land; later than that loses again).
+            // after the first 32-wide half of the slab (their copies still have half a k-step to land).
             const bool late = (NWAVES == 8) && (p.variant >= 1) && (wave >= 4);
-            const int late_at = (p.variant == 2) ? NSUB / 2 : NSUB / 2 - 1;
             const bool more = kt + 1 < nk;
             long aoff = 0, boff = 0;
             if (more) slab_offsets(kt + 1, aoff, boff);
             if (more && !late) stage_part(cur ^ 1, aoff, boff, -1);
             const char* sbase = smem + cur * STAGE_BYTES;
+            const int l15 = lane & 15, q4 = lane >> 4;
+            const int a16_off = (wm * TI * 32 + l15) * RB, b16_off = A_BYTES + (wn * TJ * 32 + l15) * RB;
 #pragma unroll
-            for (int s = 0; s < NSUB; ++s) {
-                const int coff = ((2 * s + hi) ^ swz) * 16;
-                opx8 af[TI], bf[TJ];
-#pragma unroll
-                for (int i = 0; i < TI; ++i) af[i] = *(const opx8*)(sbase + a_row_off + i * 32 * RB + coff);
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) bf[j] = *(const opx8*)(sbase + b_row_off + j * 32 * RB + coff);
+            for (int s = 0; s < BK / 32; ++s) {   // 32-wide k halves
+                const int coff = ((4 * s + q4) ^ (CHUNKS == 8 ? ((l15 >> 1) & 7) : ((l15 >> 2) & 3))) * 16;
+                opx8 af[TI][2], bf[TJ][2];
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
-                    for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
-                if (s == late_at) {
+                    for (int a = 0; a < 2; ++a) af[i][a] = *(const opx8*)(sbase + a16_off + (i * 32 + a * 16) * RB + coff);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) bf[j][b2] = *(const opx8*)(sbase + b16_off + (j * 32 + b2 * 16) * RB + coff);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b2 = 0; b2 < 2; ++b2) acc[i][j][2 * a + b2] = mfma16(af[i][a], bf[j][b2], acc[i][j][2 * a + b2]);
+                if (s == 0) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (more && late) stage_part(cur ^ 1, aoff, boff, -1);
                     __builtin_amdgcn_sched_barrier(0);
@@ -409,8 +320,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     constexpr int GW = TJ >= 2 ? 64 : 32;      // columns per epilogue group
     constexpr int GJ = GW / 32;                // MFMA tiles per group
     constexpr int NG = TJ / GJ;                // groups per wave-tile row block
-    static_assert(NWAVES * 32 * GW * 4 <= 2 * STAGE_BYTES, "epilogue slabs must fit in the stage buffers");
-    float* slab = (float*)(smem + wave * (32 * GW * 4));
+    constexpr int SW = GW + 4;                 // slab row stride in floats: the four 16-lane quarters of a 16x16 dump (rows 4 apart) hit disjoint banks
+    static_assert(NWAVES * 32 * SW * 4 <= 2 * STAGE_BYTES, "epilogue slabs must fit in the stage buffers");
+    float* slab = (float*)(smem + wave * (32 * SW * 4));
     const int flags = p.flags;
     const int mbase = m0 + wm * TI * 32;
     const int nwave = n0 + wn * TJ * 32;
@@ -419,7 +331,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
 #pragma unroll
         for (int jj = 0; jj < GJ; ++jj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) slab[crow32(r, hi) * GW + jj * 32 + l31] = acc[i][g * GJ + jj][r];
+            for (int r = 0; r < 16; ++r) {
+                const int ab = r >> 2, rr = r & 3;   // D[4*(lane>>4)+rr][lane&15] of sub-tile (a, b)
+                slab[(16 * (ab >> 1) + 4 * (lane >> 4) + rr) * SW + jj * 32 + 16 * (ab & 1) + (lane & 15)] = acc[i][g * GJ + jj][ab][rr];
+            }
     };
 
     if constexpr (EPI == EPI_SWIGLU) {
@@ -444,8 +359,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 for (int k = 0; k < 4; ++k) {
                     const int row = k * 8 + rsub;
                     const int m = mbase + i * 32 + row;
-                    const float4 x1 = *(const float4*)(slab + row * GW + 4 * c8);
-                    const float4 x2 = *(const float4*)(slab + row * GW + 32 + 4 * c8);
+                    const float4 x1 = *(const float4*)(slab + row * SW + 4 * c8);
+                    const float4 x2 = *(const float4*)(slab + row * SW + 32 + 4 * c8);
                     if (m < p.M && nval) {
                         float4 gt;
                         float t;
@@ -477,7 +392,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             for (int k = 0; k < 32 / RPI; ++k) {
                 const int row = k * RPI + rsub;
                 const int m = mbase + i * 32 + row;
-                const float4 v = *(const float4*)(slab + row * GW + 4 * cg);
+                const float4 v = *(const float4*)(slab + row * SW + 4 * cg);
                 float part = __builtin_fmaxf(v.x + bias4.x, 0.f) * tail4.x + __builtin_fmaxf(v.y + bias4.y, 0.f) * tail4.y +
                              __builtin_fmaxf(v.z + bias4.z, 0.f) * tail4.z + __builtin_fmaxf(v.w + bias4.w, 0.f) * tail4.w;
 #pragma unroll
@@ -520,8 +435,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
 #pragma unroll
                     for (int k = 0; k < 32 / RPI; ++k) {
                         const int row = k * RPI + rsub;
-                        float4 v0 = *(const float4*)(slab + row * GW + 8 * cg);
-                        float4 v1 = *(const float4*)(slab + row * GW + 8 * cg + 4);
+                        float4 v0 = *(const float4*)(slab + row * SW + 8 * cg);
+                        float4 v1 = *(const float4*)(slab + row * SW + 8 * cg + 4);
                         v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
                         v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
                         if constexpr (EPI == EPI_GELU) {
@@ -597,7 +512,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 if (pad) walk = pad_start(p, (uint32_t)mrow);
 #pragma unroll
                 for (int k = 0; k < NKI; ++k) {
-                    float4 v = *(const float4*)(slab + (k * RPI + rsub) * GW + 4 * cg);
+                    float4 v = *(const float4*)(slab + (k * RPI + rsub) * SW + 4 * cg);
                     v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                     if constexpr (EPI == EPI_GELU) {
                         v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
@@ -666,8 +581,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 for (int k = 0; k < 32 / RPI; ++k) {
                     const int row = k * RPI + rsub;
                     const int m = mbase + i * 32 + row;
-                    float4 v0 = *(const float4*)(slab + row * GW + 8 * cg);
-                    float4 v1 = *(const float4*)(slab + row * GW + 8 * cg + 4);
+                    float4 v0 = *(const float4*)(slab + row * SW + 8 * cg);
+                    float4 v1 = *(const float4*)(slab + row * SW + 8 * cg + 4);
                     v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
                     v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
                     if constexpr (EPI == EPI_GELU) {
@@ -774,7 +689,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             for (int k = 0; k < NKI; ++k) {
                 const int row = k * RPI + rsub;
                 const int m = mbase + i * 32 + row;
-                float4 v = *(const float4*)(slab + row * GW + 4 * cg);
+                float4 v = *(const float4*)(slab + row * SW + 4 * cg);
                 v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                 if constexpr (EPI == EPI_GELU) {
                     v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
@@ -835,7 +750,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
 }
 
 static int g_group_override = 0;  // debug: force the column-group width (0 = model)
-static int g_long_k_cfg = 3;       // tile for K > 2048 (A/B switch ADA_IGEMM_LONGK: 3 = 8 waves, 8 = 4-wave pipelined)
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
 int launch_cfg(IgemmDev& d, hipStream_t stream) {
@@ -893,7 +807,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
     else {
         // large problems: the 256x256 tile (best MFMA efficiency); small ones (single images, ViT-S/B at small batch)
         // would leave most CUs idle with it, so pick the tile that minimises the quantised time estimate
-        cfg = (d.K <= 2048) ? short_k_cfg : g_long_k_cfg;
+        cfg = (d.K <= 2048) ? short_k_cfg : 3;
         double best = tile_time(d.M, d.N, 256, 256, 1, 1.0);
         const double t2 = tile_time(d.M, d.N, 256, 128, 1, 0.90), t4 = tile_time(d.M, d.N, 128, 128, 2, 0.85),
                      t1 = tile_time(d.M, d.N, 128, 64, 3, 0.65);
@@ -917,7 +831,6 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
             case 4: return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
             case 5: return launch_cfg<128, 256, 32, 2, 2, EPI>(d, s);
             case 7: return launch_cfg<512, 128, 64, 8, 1, EPI>(d, s);
-            case 8: return launch_cfg<256, 256, 64, 2, 2, EPI>(d, s);
             default: return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
         }
     }
@@ -1028,8 +941,6 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
         if (va) g_variant = atoi(va);
         const char* sk = getenv("ADA_IGEMM_SHORTK");
         g_short_k_cfg = sk ? atoi(sk) : 3;
-        const char* lk = getenv("ADA_IGEMM_LONGK");
-        if (lk) g_long_k_cfg = atoi(lk);
     }
     const int force = g_force_tile, short_k_cfg = g_short_k_cfg;
     d.dbg = g_dbg;

@@ -327,15 +327,23 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     const int mbase = m0 + wm * TI * 32;
     const int nwave = n0 + wn * TJ * 32;
 
+    // D[4*(lane>>4)+rr][lane&15] of sub-tile (a, b) -> slab row 16a + 4*(lane>>4) + rr, column 32jj + 16b + (lane&15): four rows per
+    // lane and sub-tile, written as two ds_write2_b32 (rows rr, rr+1) off one base address per row half a (hipcc pairs only a
+    // third of the stores on its own)
+    const unsigned slab_lds = (unsigned)(size_t)slab + (unsigned)((4 * (lane >> 4) * SW + (lane & 15)) * 4);
     auto dump = [&](int i, int g) {
 #pragma unroll
         for (int jj = 0; jj < GJ; ++jj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ab = r >> 2, rr = r & 3;   // D[4*(lane>>4)+rr][lane&15] of sub-tile (a, b)
-                slab[(16 * (ab >> 1) + 4 * (lane >> 4) + rr) * SW + jj * 32 + 16 * (ab & 1) + (lane & 15)] = acc[i][g * GJ + jj][ab][rr];
+            for (int ab = 0; ab < 4; ++ab) {
+                const f32x4 v = acc[i][g * GJ + jj][ab];
+                const unsigned base = slab_lds + (unsigned)((ab >> 1) * 16 * SW * 4);
+                const int col = jj * 32 + 16 * (ab & 1);   // in floats; the two offsets of ds_write2_b32 count 4-byte units (< 256)
+                asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(base), "v"(v[0]), "v"(v[1]), "i"(col), "i"(col + SW) : "memory");
+                asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(base), "v"(v[2]), "v"(v[3]), "i"(col + 2 * SW), "i"(col + 3 * SW) : "memory");
             }
     };
+    static_assert((GJ - 1) * 32 + 16 + 3 * SW < 256, "ds_write2_b32 offsets are 8 bits");
 
     if constexpr (EPI == EPI_SWIGLU) {
         // packer interleaved the w12 rows in 32-wide groups: columns [0,32) of a 64-column group = x1, [32,64) = x2

@@ -13,7 +13,7 @@ import json
 import os
 import sys
 
-FAMILIES = (("igemm", "igemm_kernel"), ("attention", "attention_kernel"), ("layernorm", "layernorm_kernel"), ("bilinear", "bilinear_kernel"))
+FAMILIES = (("igemm", "igemm_kernel"), ("attention", "attention_kernel"), ("layernorm", "layernorm_kernel"), ("bilinear", "bilinear"))
 
 
 def per_family(path, counter):

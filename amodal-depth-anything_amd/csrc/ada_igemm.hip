@@ -9,9 +9,9 @@
 //                                                            of another -- short-K transformer GEMMs (qkv, proj, fc1)
 //     256 x 128 x 64, 8 waves (4 x 2)                      -- N = 128 (output_conv1)
 //     128 x  64 / 256 x 32 x 64, 4 waves                   -- narrow outputs (ViT-S projections, the 32-channel tail conv)
-// A and W k-slabs (rows of BK operands = 128 or 64 B) go HBM/L2 -> LDS with 16-byte global_load_lds (no VGPR round
+// A and W k-slabs (rows of BK operands = 128 or 64 B) go HBM/L2 -> LDS with 16-byte buffer loads to LDS (buffer_load_dwordx4 ... lds) (no VGPR round
 // trip), two LDS stages, one barrier per k-step; the loads of slab t+1 are in flight during the MFMAs of slab t.
-// LDS rows are stored linearly (global_load_lds writes wave base + lane*16) but each lane *fetches* chunk
+// LDS rows are stored linearly (the LDS-DMA writes wave base + lane*16) but each lane *fetches* chunk
 // c ^ key(row) of its row (key = (row>>1)&7 for 128-byte rows, (row>>2)&3 for 64-byte rows) and the fragment reads
 // apply the same XOR, so every ds_read_b128 lane group hits 16 distinct 16-byte bank slots (0 conflicts measured;
 // cdna_hip_programming.md T2 / rule 21).
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     constexpr int A_BYTES = BM * RB;
     constexpr int B_BYTES = BN * RB;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int ROWS_PER_PASS = NT / CHUNKS;  // rows copied by one workgroup-wide global_load_lds pass
+    constexpr int ROWS_PER_PASS = NT / CHUNKS;  // rows copied by one workgroup-wide LDS-DMA pass
     constexpr int A_IT = BM / ROWS_PER_PASS;
     constexpr int B_IT = BN / ROWS_PER_PASS;
     static_assert(BK == 64 || BK == 32, "BK is 64 or 32");
@@ -179,28 +179,35 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     // ---- per-thread staging addresses --------------------------------------------------
     const int srow = tid / CHUNKS;                                  // row inside a staging pass
     const int gchunk = (tid % CHUNKS) ^ ((tid >> 4) & (CHUNKS - 1));  // swizzled source chunk; key(row) == (tid>>4)&(CHUNKS-1)
-    const op_t* a_ptr[A_IT];
-    const op_t* b_ptr[B_IT];
+    // Every copy address is (workgroup-uniform tile base + k-step offset) + a 32-bit per-lane byte offset that never changes.
+    // The copies are buffer loads to LDS (buffer_load_dwordx4 ... offen lds): tile base in a buffer resource (SGPRs), k-step
+    // offset in the scalar offset, lane offset in one VGPR -- a copy is s_mov m0 + the load, no 64-bit VALU add per copy.
+    auto a_row_base = [&](uint32_t m) -> long {   // element offset of GEMM row m's first operand element
+        if (p.a_mode == ADA_A_PLAIN) return (long)m * p.lda;
+        uint32_t b, rem, y, x;
+        fast_divmod(m, p.dHoWo, b, rem);
+        fast_divmod(rem, p.dWo, y, x);
+        return (((long)b * p.Hp + (long)y * p.stride) * p.Wp + (long)x * p.stride) * p.lda;
+    };
+    const uint32_t m_first = (uint32_t)m0 < (uint32_t)p.M ? (uint32_t)m0 : (uint32_t)p.M - 1;
+    const long a_tile_el = a_row_base(m_first);                          // uniform: rows of the tile only go up from here
+    const op_t* a_tile = p.A + a_tile_el;
+    const op_t* b_tile = p.W + (long)(n0 < p.N ? n0 : p.N - 1) * p.K;
+    // raw buffer resources: stride 0, 2 GiB window above the tile base (nothing relies on out-of-range behaviour), dword 3 = 0x20000
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_tile, 0, 0x7fffffff, 0x20000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)b_tile, 0, 0x7fffffff, 0x20000);
+    uint32_t a_off[A_IT], b_off[B_IT];                                    // bytes
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         uint32_t m = (uint32_t)(m0 + it * ROWS_PER_PASS + srow);
         if (m >= (uint32_t)p.M) m = (uint32_t)p.M - 1;
-        long base;
-        if (p.a_mode == ADA_A_PLAIN) {
-            base = (long)m * p.lda;
-        } else {
-            uint32_t b, rem, y, x;
-            fast_divmod(m, p.dHoWo, b, rem);
-            fast_divmod(rem, p.dWo, y, x);
-            base = (((long)b * p.Hp + (long)y * p.stride) * p.Wp + (long)x * p.stride) * p.lda;
-        }
-        a_ptr[it] = p.A + base + gchunk * 8;
+        a_off[it] = (uint32_t)((a_row_base(m) - a_tile_el + gchunk * 8) * 2);
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         int n = n0 + it * ROWS_PER_PASS + srow;
         if (n >= p.N) n = p.N - 1;
-        b_ptr[it] = p.W + (long)n * p.K + gchunk * 8;
+        b_off[it] = (uint32_t)(((long)(n - (n0 < p.N ? n0 : p.N - 1)) * p.K + gchunk * 8) * 2);
     }
 
     // k-step kt -> element offsets of its A and W slabs (wave-uniform scalars)
@@ -223,14 +230,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             if (part < 0 || (it % NSUB) == part)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[it] + aoff),
-                                                 (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, (int)a_off[it],
+                                                         (int)(aoff * 2), 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             if (part < 0 || ((it + NSUB / 2) % NSUB) == part)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[it] + boff),
-                                                 (__attribute__((address_space(3))) void*)(sb + it * (NT * 16)), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(sb + it * (NT * 16)), 16, (int)b_off[it],
+                                                         (int)(boff * 2), 0, 0);
         }
     };
 

@@ -1,16 +1,16 @@
 // Implicit-GEMM contraction with fused epilogues (see include/ada_hip.h: ada_igemm).
 //
-// Tiling (gfx950).  A workgroup computes a BM x BN output tile in k-steps of BK; each wave owns TI x TJ MFMA
-// tiles of 32x32 (v_mfma_f32_32x32x16, fp32 accumulate).  Tile shapes:
-//     256 x 256 x 64, 8 waves (2 x 4), wave tile 128 x 64  -- 1 workgroup / CU, 128 FLOP per LDS byte staged: best when the
-//                                                            k-loop is long (3x3 convs, fc2)
-//     128 x 256 x 32, 4 waves (2 x 2), wave tile  64 x 128 -- 2-3 independent workgroups / CU (48 KB LDS each): the epilogue
-//                                                            (HBM-latency bound, ~10 B/clk/CU) of one tile overlaps the MFMAs
-//                                                            of another -- short-K transformer GEMMs (qkv, proj, fc1)
-//     256 x 128 x 64, 8 waves (4 x 2)                      -- N = 128 (output_conv1)
-//     128 x  64 / 256 x 32 x 64, 4 waves                   -- narrow outputs (ViT-S projections, the 32-channel tail conv)
-// A and W k-slabs (rows of BK operands = 128 or 64 B) go HBM/L2 -> LDS with 16-byte buffer loads to LDS (buffer_load_dwordx4 ... lds) (no VGPR round
-// trip), two LDS stages, one barrier per k-step; the loads of slab t+1 are in flight during the MFMAs of slab t.
+// Tiling (gfx950).  A workgroup computes a BM x BN output tile in k-steps of BK; each wave owns TI x TJ blocks of 32x32, each
+// block four 16x16 sub-tiles of v_mfma_f32_16x16x32 (fp32 accumulate) -- the MFMA flavour that sustains the higher rate under the
+// chip's power cap.  Tile shapes:
+//     256 x 256 x 64, 8 waves (2 x 4), wave tile 128 x 64  -- the default: 1 workgroup / CU, 128 FLOP per LDS byte staged
+//     512 x 128 x 64, 8 waves (8 x 1), wave tile  64 x 128 -- N <= 128 with plenty of rows (output_conv1)
+//     256 x 128 x 64, 8 waves (4 x 2)                      -- N <= 128 otherwise
+//     128 x 128 x 64 / 128 x 64 x 64 / 256 x 32 x 64, 4 waves -- small problems (single images, ViT-S/B at small batch: chosen by a
+//                                                            quantised time estimate) and narrow outputs (32-channel tail conv)
+//     128 x 256 x 32, 4 waves                              -- A/B only (ADA_IGEMM_SHORTK=5): co-resident workgroups measured slower
+// A and W k-slabs (rows of BK operands = 128 or 64 B) go HBM/L2 -> LDS with 16-byte buffer loads to LDS (buffer_load_dwordx4 ... lds,
+// no VGPR round trip), two LDS stages, one barrier per k-step; the loads of slab t+1 are in flight during the MFMAs of slab t.
 // LDS rows are stored linearly (the LDS-DMA writes wave base + lane*16) but each lane *fetches* chunk
 // c ^ key(row) of its row (key = (row>>1)&7 for 128-byte rows, (row>>2)&3 for 64-byte rows) and the fragment reads
 // apply the same XOR, so every ds_read_b128 lane group hits 16 distinct 16-byte bank slots (0 conflicts measured;

@@ -222,11 +222,11 @@ __global__ __launch_bounds__(256) void bilinear_kernel(BilinearArgs p) {
 }
 
 // LDS-tiled variant for up-sampling wide-channel maps (the DPT fusion path: 128 / 256 channels).  One workgroup produces an
-// 8 x 32 tile of output pixels for a chunk of 128 channels.  The source patch the tile touches (at most 6 x 20 pixels at the
-// scales used here) is copied ONCE into LDS by global_load_lds (16 B per lane, lane-linear: pixel-major, 512 B per pixel), then
+// 8 x 16 tile of output pixels for a chunk of 128 channels (8 x 16 measured best among 4x16 .. 8x64: 36 KB of LDS, four workgroups
+// per CU overlap each other's staging).  The source patch the tile touches (at most 6 x 12 pixels at the scales used here) is copied ONCE into LDS by global_load_lds (16 B per lane, lane-linear: pixel-major, 512 B per pixel), then
 // every output reads its four taps from LDS.  The per-pixel kernel above re-fetches each source pixel ~12x through L2 (the
 // workgroups sharing a source row run on different CUs) and tops out near 3 TB/s; this one reads the source about once.
-constexpr int BT_TH = 8, BT_TW = 32, BT_CG = 32;   // tile height / width in output pixels, float4 channel groups per chunk
+constexpr int BT_TH = 8, BT_TW = 16, BT_CG = 32;   // tile height / width in output pixels, float4 channel groups per chunk
 
 __global__ __launch_bounds__(256) void bilinear_tiled_kernel(BilinearArgs p, int ph, int pw, int nchunk) {
     extern __shared__ __attribute__((aligned(16))) char bl_smem[];
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void bilinear_tiled_kernel(BilinearArgs p, int
     // ---- 256 output pixels, 8 per pass --------------------------------------------------------------------------
 #pragma unroll 4
     for (int it = 0; it < BT_TH * BT_TW / 8; ++it) {
-        const int py = it >> 2, px = ((it & 3) << 3) + psub;
+        const int py = it / (BT_TW / 8), px = (it % (BT_TW / 8)) * 8 + psub;
         const int y = ty0 + py, x = tx0 + px;
         if (y >= p.ho || x >= p.wo) continue;
         const float fy = p.sy * (float)y, fx = p.sx * (float)x;
@@ -368,7 +368,7 @@ extern "C" int ada_bilinear_fwd(const float* in, int64_t ld_in, int32_t batch, i
     p.map_op = map_op; p.relu = relu;
     p.dC4 = make_fastdiv(p.c4); p.dWo = make_fastdiv(wo); p.dHo = make_fastdiv(ho);
     ADA_REQUIRE(ho <= 65535 && batch <= 65535, ADA_EUNSUPPORTED, "ada_bilinear_fwd: ho / batch exceed the grid limits");
-    // LDS-tiled path: up-sampling, channels in chunks of 128, source patch of an 8 x 32 output tile within 64 KiB
+    // LDS-tiled path: up-sampling, channels in chunks of 128, source patch of an 8 x 16 output tile within 64 KiB
     // exact patch extent: the same fp32 expressions the kernel evaluates, maximised over the tile rows / columns
     auto extent = [](float sc, int n_in, int n_out, int tile) {
         int best = 1;

@@ -824,8 +824,10 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
         // would leave most CUs idle with it, so pick the tile that minimises the quantised time estimate
         cfg = (d.K <= 2048) ? short_k_cfg : 3;
         double best = tile_time(d.M, d.N, 256, 256, 1, 1.0);
-        const double t2 = tile_time(d.M, d.N, 256, 128, 1, 0.90), t4 = tile_time(d.M, d.N, 128, 128, 2, 0.85),
-                     t1 = tile_time(d.M, d.N, 128, 64, 3, 0.65);
+        // relative main-loop efficiencies re-fitted after the move to 16x16x32 MFMAs (tools/autotune_shapes.py at B = 1 and 4:
+        // the 128x64 tile with three co-resident workgroups wins more of the small problems than it used to)
+        const double t2 = tile_time(d.M, d.N, 256, 128, 1, 0.72), t4 = tile_time(d.M, d.N, 128, 128, 2, 0.85),
+                     t1 = tile_time(d.M, d.N, 128, 64, 3, 0.80);
         if (t2 < 0.95 * best) { best = t2; cfg = 2; }
         if (t4 < 0.95 * best) { best = t4; cfg = 4; }
         if (EPI != EPI_SWIGLU && t1 < 0.95 * best) { best = t1; cfg = 1; }

@@ -4,9 +4,9 @@
 // block four 16x16 sub-tiles of v_mfma_f32_16x16x32 (fp32 accumulate) -- the MFMA flavour that sustains the higher rate under the
 // chip's power cap.  Tile shapes:
 //     256 x 256 x 64, 8 waves (2 x 4), wave tile 128 x 64  -- the default: 1 workgroup / CU, 128 FLOP per LDS byte staged
-//     512 x 128 x 64, 8 waves (8 x 1), wave tile  64 x 128 -- N <= 128 with plenty of rows (output_conv1)
-//     256 x 128 x 64, 8 waves (4 x 2)                      -- N <= 128 otherwise
-//     128 x 128 x 64 / 128 x 64 x 64 / 256 x 32 x 64, 4 waves -- small problems (single images, ViT-S/B at small batch: chosen by a
+//     128 x 128 x 64, 4 waves, two workgroups per CU        -- N <= 128 (output_conv1, ViT-B head) and mid-size problems
+//     512 x 128 x 64 / 256 x 128 x 64, 8 waves             -- selectable (ADA_IGEMM_TILE=7 / 2); measured slower than 128 x 128 at N = 128
+//     128 x 64 x 64 / 256 x 32 x 64, 4 waves                 -- small problems (single images, ViT-S/B at small batch: chosen by a
 //                                                            quantised time estimate) and narrow outputs (32-channel tail conv)
 //     128 x 256 x 32, 4 waves                              -- A/B only (ADA_IGEMM_SHORTK=5): co-resident workgroups measured slower
 // A and W k-slabs (rows of BK operands = 128 or 64 B) go HBM/L2 -> LDS with 16-byte buffer loads to LDS (buffer_load_dwordx4 ... lds,
@@ -818,7 +818,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
     int cfg;
     if (d.N <= 32) cfg = 0;
     else if (d.N <= 64) cfg = 1;
-    else if (d.N <= 128) cfg = (d.M >= 512 * 512) ? 7 : 2;   // plenty of rows: the 512x128 tile stages fewer bytes per FLOP
+    else if (d.N <= 128) cfg = 4;   // two co-resident 128x128 workgroups per CU: -12 % vs the 512x128 / 256x128 tiles at every batch size
     else {
         // large problems: the 256x256 tile (best MFMA efficiency); small ones (single images, ViT-S/B at small batch)
         // would leave most CUs idle with it, so pick the tile that minimises the quantised time estimate
@@ -830,7 +830,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
                      t1 = tile_time(d.M, d.N, 128, 64, 3, 0.80);
         if (t2 < 0.95 * best) { best = t2; cfg = 2; }
         if (t4 < 0.95 * best) { best = t4; cfg = 4; }
-        if (EPI != EPI_SWIGLU && t1 < 0.95 * best) { best = t1; cfg = 1; }
+        if (EPI != EPI_SWIGLU && t1 < 0.90 * best) { best = t1; cfg = 1; }   // the small tile loses on long k-loops at equal estimate
     }
     if (d.M < 256 && cfg >= 2 && cfg != 4) cfg = 4;
     if (force >= 0) cfg = force;

@@ -280,10 +280,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             }
             if (p.dbg && kt == 0) t_first = __builtin_amdgcn_s_memtime();
             // The two waves that share a SIMD (w and w+4 of an 8-wave workgroup) leave the barrier together; if both issued
-            // their global->LDS copies first, neither would have MFMAs in flight for ~500 cycles.  Variant 1 (default, +3 %
-            // measured: profiles/r01_e_gemm_stagger_ab.txt) staggers them: waves 0-3 copy before their MFMAs, waves 4-7
-            // after the first 32-wide half of the slab (their copies still have half a k-step to land).
-            const bool late = (NWAVES == 8) && (p.variant >= 1) && (wave >= 4);
+            // their global->LDS copies first, neither would have MFMAs in flight for a few hundred cycles.  One group therefore
+            // issues its copies after the first 32-wide half of the slab (they still have half a k-step to land).  Variant 4
+            // (default): waves 0-3 are the late group; variant 1: waves 4-7; 0: nobody (-3 %); 2: everybody (-5 % on long K).
+            // Variant 4 over 1: qkv -1.7 %, fc2 -3 %, end to end +1.6 % (profiles/r01_l_gemm_copy_stagger_variants.txt).
+            const bool late = (NWAVES == 8) && ((p.variant == 1 && wave >= 4) || p.variant == 2 || (p.variant == 4 && wave < 4));
             const bool more = kt + 1 < nk;
             long aoff = 0, boff = 0;
             if (more) slab_offsets(kt + 1, aoff, boff);
@@ -856,7 +857,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
 }  // namespace
 
 static unsigned long long* g_dbg = nullptr;
-static int g_force_tile = -1, g_short_k_cfg = 3, g_variant = 1;
+static int g_force_tile = -1, g_short_k_cfg = 3, g_variant = 4;
 static bool g_env_read = false;
 // debug hook (not part of the stable ABI): override the tile configuration (-1 = heuristic)
 extern "C" void ada_debug_set_tile(int cfg) { g_force_tile = cfg; g_env_read = true; }

@@ -23,6 +23,8 @@
 // fp32 (16 B) and operand-typed (8 B) stores are contiguous 128-256 B row segments.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <mutex>
+#include <type_traits>
 #include "ada_common.h"
 
 namespace {
@@ -124,8 +126,9 @@ ADA_DEV opx4 pack4(float4 v) {
     return o;
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, bool PHASED = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && BM * BN == 256 * 256) ? 1 : 2) void igemm_kernel(IgemmDev p) {
+    static_assert(!PHASED || (BM == 256 && BN == 256 && BK == 64 && WAVES_M == 2 && WAVES_N == 4), "the phased main loop is written for the 256x256x64 tile, 2 x 4 waves");
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int NT = NWAVES * 64;
     constexpr int TI = BM / (WAVES_M * 32);
@@ -257,6 +260,166 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 for (int r = 0; r < 4; ++r) acc[i][j][ab][r] = 0.0f;
 
     const int nk = p.K / BK;
+    if constexpr (PHASED) {
+        // ---- phased main loop (cdna_hip_programming.md section 5, "the 256^2 8-phase template"; T3 + T4 + T5) -------------------
+        // A k-tile is computed in four phases, one 64 x 32 quadrant of the wave's 128 x 64 output tile each (16 MFMAs over the
+        // whole BK = 64).  A phase is two barrier intervals:   L: fragment reads for this quadrant + ONE half-tile of LDS-DMA copies
+        //                                                      M: s_setprio 1, 16 MFMAs, s_setprio 0
+        // and the two wave groups (wm = 0: waves 0-3, wm = 1: waves 4-7; waves w and w + 4 share a SIMD) run one interval apart, so on
+        // every SIMD one wave issues MFMAs while its partner reads LDS and issues copies.  Quadrant order (A-lo,B-lo) (A-lo,B-hi)
+        // (A-hi,B-hi) (A-hi,B-lo): 12 / 4 / 8 / 0 fragment reads; the B regions of a stage are last read in phase 1, the A regions
+        // in phase 2.  Copies are never drained inside the loop: the half-tiles of k-tile t+1 / t+2 are issued 3-8 intervals before
+        // their first read and each group waits ONCE per k-tile with a counted vmcnt that leaves its youngest copies in flight.
+        //   issue schedule (X(u) = half-tile X of k-tile u, stage u & 1), chosen so that every copy is issued at least one barrier
+        //   after the last read of the region it overwrites has RETIRED (reads retire in the M interval after their L interval):
+        //       group 1:  p0 A0(t+1)   p1 A1(t+1)   p2 B0(t+2)   p3 B1(t+2)   wait vmcnt(4) at the end of L(p3)
+        //       group 0:  p0 B1(t+1)   p1 A0(t+1)   p2 A1(t+1)   p3 B0(t+2)   wait vmcnt(2) at the end of M(p3)
+        //   both waits end at the same barrier, after which k-tile t+1 is complete in LDS for every wave.
+        const int wm_ = wave / WAVES_N, wn_ = wave % WAVES_N;
+        const bool g1 = wm_ == 1;   // wave-uniform
+        const int l15 = lane & 15, q4 = lane >> 4;
+        const unsigned lds0 = (unsigned)(size_t)smem;
+        unsigned a_base[2], b_base[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const unsigned coff = (unsigned)(((4 * s2 + q4) ^ ((l15 >> 1) & 7)) * 16);
+            a_base[s2] = lds0 + (unsigned)((wm_ * 128 + l15) * RB) + coff;
+            b_base[s2] = lds0 + (unsigned)(A_BYTES + (wn_ * 64 + l15) * RB) + coff;
+        }
+        auto copy_half = [&](int stage, int is_b, int h, long aoff, long boff) {   // one half-tile = passes 2h, 2h+1
+            char* dst = smem + stage * STAGE_BYTES + wave * 1024 + (is_b ? A_BYTES : 0);
+            if (is_b) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(dst + (2 * h + it) * (NT * 16)), 16,
+                                                             (int)(h ? b_off[2 + it] : b_off[it]), (int)(boff * 2), 0, 0);
+            } else {
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(dst + (2 * h + it) * (NT * 16)), 16,
+                                                             (int)(h ? a_off[2 + it] : a_off[it]), (int)(aoff * 2), 0, 0);
+            }
+        };
+        opx8 af[2][2][2], bf[2][2][2];   // [block in quadrant][16-row half][k half]
+        auto read_a = [&](auto stage_tag, auto qi_tag) {
+            (void)af; (void)a_base;   // asm operands alone do not make a generic lambda capture (clang 22)
+            constexpr int ST = decltype(stage_tag)::value, QI = decltype(qi_tag)::value;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[ii][a][s2]) : "v"(a_base[s2] + (unsigned)(ST * STAGE_BYTES)), "i"(((2 * QI + ii) * 32 + a * 16) * RB));
+        };
+        auto read_b = [&](auto stage_tag, auto qj_tag) {
+            (void)bf; (void)b_base;
+            constexpr int ST = decltype(stage_tag)::value, QJ = decltype(qj_tag)::value;
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[QJ][b2][s2]) : "v"(b_base[s2] + (unsigned)(ST * STAGE_BYTES)), "i"((QJ * 32 + b2 * 16) * RB));
+        };
+        auto mfma_quadrant = [&](auto qi_tag, auto qj_tag) {
+            constexpr int QI = decltype(qi_tag)::value, QJ = decltype(qj_tag)::value;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b2 = 0; b2 < 2; ++b2)
+                            acc[2 * QI + ii][QJ][2 * a + b2] = mfma16(af[ii][a][s2], bf[QJ][b2][s2], acc[2 * QI + ii][QJ][2 * a + b2]);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        // barrier that ends an L interval: the fragment reads issued in it retire right behind it
+        auto l_to_m = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto m_to_l = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+
+        auto k_tile = [&](auto stage_tag, int t) {
+            constexpr int ST = decltype(stage_tag)::value;       // stage of k-tile t
+            const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+            long a1 = 0, b1 = 0, a2 = 0, b2o = 0;
+            if (has1) slab_offsets(t + 1, a1, b1);
+            if (has2) slab_offsets(t + 2, a2, b2o);
+            // ---- phase 0: quadrant (A-lo, B-lo) ----
+            read_b(stage_tag, I0{});
+            read_a(stage_tag, I0{});
+            if (has1) { if (g1) copy_half(ST ^ 1, 0, 0, a1, b1); else copy_half(ST ^ 1, 1, 1, a1, b1); }
+            l_to_m();
+            mfma_quadrant(I0{}, I0{});
+            m_to_l();
+            // ---- phase 1: (A-lo, B-hi) ----
+            read_b(stage_tag, I1{});
+            if (has1) { if (g1) copy_half(ST ^ 1, 0, 1, a1, b1); else copy_half(ST ^ 1, 0, 0, a1, b1); }
+            l_to_m();
+            mfma_quadrant(I0{}, I1{});
+            m_to_l();
+            // ---- phase 2: (A-hi, B-hi) ----
+            read_a(stage_tag, I1{});
+            if (g1) { if (has2) copy_half(ST, 1, 0, a2, b2o); } else { if (has1) copy_half(ST ^ 1, 0, 1, a1, b1); }
+            l_to_m();
+            mfma_quadrant(I1{}, I1{});
+            m_to_l();
+            // ---- phase 3: (A-hi, B-lo), no fragment reads ----
+            if (has2) { if (g1) copy_half(ST, 1, 1, a2, b2o); else copy_half(ST, 1, 0, a2, b2o); }
+            if (g1 && has1) {
+                if (has2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            l_to_m();
+            mfma_quadrant(I1{}, I0{});
+            if (!g1 && has1) {
+                if (has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            m_to_l();
+        };
+
+        // prologue: k-tile 0 completely, plus the half-tiles of k-tile 1 that the steady-state schedule issued "before the loop"
+        {
+            long a0o, b0o, a1 = 0, b1 = 0;
+            slab_offsets(0, a0o, b0o);
+            copy_half(0, 0, 0, a0o, b0o);
+            copy_half(0, 0, 1, a0o, b0o);
+            copy_half(0, 1, 0, a0o, b0o);
+            copy_half(0, 1, 1, a0o, b0o);
+            if (nk > 1) {
+                slab_offsets(1, a1, b1);
+                copy_half(1, 1, 0, a1, b1);
+                if (g1) copy_half(1, 1, 1, a1, b1);
+            }
+            if (nk > 1) {
+                if (g1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            if (g1) __builtin_amdgcn_s_barrier();     // group 1 runs one interval behind group 0
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int t = 0; t < nk; t += 2) {
+            k_tile(I0{}, t);
+            if (t + 1 < nk) k_tile(I1{}, t + 1);
+        }
+        if (!g1) __builtin_amdgcn_s_barrier();        // balances group 1's extra barrier
+    } else {
     {
         long aoff, boff;
         slab_offsets(0, aoff, boff);
@@ -320,6 +483,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             }
         }
     }
+    }  // !PHASED
 
     // ---- epilogue: transpose through a wave-private LDS slab, then float4 per lane ----------------
     // The wave tile is walked in 32-row x GW-column groups (GW = 64, or 32 for the narrow tiles).
@@ -766,8 +930,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
 }
 
 static int g_group_override = 0;  // debug: force the column-group width (0 = model)
+static thread_local int g_last_tile = -1;   // tile configuration of the calling thread's most recent launch (ada_debug_last_tile)
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, bool PHASED = false>
 int launch_cfg(IgemmDev& d, hipStream_t stream) {
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int SMEM = 2 * (BM + BN) * BK * 2;
@@ -789,14 +954,15 @@ int launch_cfg(IgemmDev& d, hipStream_t stream) {
         }
         d.group_n = g_group_override > 0 ? (g_group_override < d.tiles_n ? g_group_override : d.tiles_n) : gbest;
     }
-    auto kern = igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, EPI>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    auto kern = igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, EPI, PHASED>;
+    static std::once_flag attr_once;   // one per template instantiation; concurrent first calls are serialised
+    std::call_once(attr_once, [&]() {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
             (void)hipGetLastError();
         }
-        attr_done = true;
-    }
+    });
+    g_last_tile = (BM == 256 && BN == 32 ? 0 : BM == 128 && BN == 64 ? 1 : BM == 256 && BN == 128 ? 2 : BM == 256 && BN == 256 ? 3 :
+                   BM == 128 && BN == 128 ? 4 : BM == 128 && BN == 256 ? 5 : 7) + (PHASED ? 100 : 0);
     const long nblk = (long)d.tiles_m * d.tiles_n;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), SMEM, stream, d);
     return ada_check_launch("ada_igemm");
@@ -838,6 +1004,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
     if constexpr (EPI == EPI_SWIGLU) {
         if (cfg == 4 || cfg == 2) return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
         if (cfg == 5) return launch_cfg<128, 256, 32, 2, 2, EPI>(d, s);
+        if (d.variant >= 8) return launch_cfg<256, 256, 64, 2, 4, EPI, true>(d, s);
         return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
     } else if constexpr (EPI == EPI_TAIL) {
         return cfg == 0 ? launch_cfg<256, 32, 64, 4, 1, EPI>(d, s) : launch_cfg<128, 64, 64, 4, 1, EPI>(d, s);
@@ -849,20 +1016,24 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
             case 4: return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
             case 5: return launch_cfg<128, 256, 32, 2, 2, EPI>(d, s);
             case 7: return launch_cfg<512, 128, 64, 8, 1, EPI>(d, s);
-            default: return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
+            default:
+                if (d.variant >= 8) return launch_cfg<256, 256, 64, 2, 4, EPI, true>(d, s);
+                return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
         }
     }
 }
 
 }  // namespace
 
+// ---- tuning / diagnostic hooks (declared in include/ada_hip.h; process-global, not needed for correct operation) ----
 static unsigned long long* g_dbg = nullptr;
-static int g_force_tile = -1, g_short_k_cfg = 3, g_variant = 4;
+static int g_force_tile = -1, g_short_k_cfg = 3, g_variant = 8;   // variant 8: phased main loop for the 256x256 tile; 0/1/2/4: round-1 loop with its copy-stagger flavours
 static bool g_env_read = false;
 // debug hook (not part of the stable ABI): override the tile configuration (-1 = heuristic)
 extern "C" void ada_debug_set_tile(int cfg) { g_force_tile = cfg; g_env_read = true; }
 extern "C" void ada_debug_set_variant(int v) { g_variant = v; }
 extern "C" void ada_debug_set_group(int g) { g_group_override = g; }
+extern "C" int ada_debug_last_tile(void) { return g_last_tile; }
 // debug hook (not part of the stable ABI): device buffer of 8 x u64 per workgroup, or NULL to disable
 extern "C" void ada_debug_set_timestamps(void* dev_buf) { g_dbg = (unsigned long long*)dev_buf; }
 

@@ -29,6 +29,8 @@ EXPORTS = (
     "ada_abi_version", "ada_operand_dtype", "ada_last_error", "ada_igemm", "ada_attention_fwd",
     "ada_layernorm_fwd", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
     "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd",
+    "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
+    "ada_debug_set_timestamps", "ada_debug_set_attention_variant",
 )
 
 # indices into the per-image sums of ada_depth_eval_fwd (ADA_EVAL_* in include/ada_hip.h)
@@ -109,6 +111,13 @@ def load(path: Optional[str] = None):
     lib.ada_blend_fwd.restype = c_int
     lib.ada_depth_eval_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_float, c_float, c_void_p, c_void_p]
     lib.ada_depth_eval_fwd.restype = c_int
+    for name in ("ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_set_attention_variant"):
+        getattr(lib, name).argtypes = [c_int]
+        getattr(lib, name).restype = None
+    lib.ada_debug_set_timestamps.argtypes = [c_void_p]
+    lib.ada_debug_set_timestamps.restype = None
+    lib.ada_debug_last_tile.argtypes = []
+    lib.ada_debug_last_tile.restype = c_int
     if lib.ada_abi_version() != ABI_VERSION:
         raise HipExtError(f"{path}: ABI version {lib.ada_abi_version()} != binding version {ABI_VERSION}")
     _lib, _lib_path = lib, path
@@ -201,8 +210,10 @@ def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=Non
         ev = _timer.start()
         _check(load().ada_igemm(ctypes.byref(a), _stream()), "ada_igemm")
         _timer.stop("igemm", ev, 2.0 * M * N * (k_alg if k_alg is not None else K))  # algorithmic FLOP (MAC = 2)
-        return
-    _check(load().ada_igemm(ctypes.byref(a), _stream()), "ada_igemm")
+    else:
+        _check(load().ada_igemm(ctypes.byref(a), _stream()), "ada_igemm")
+    if _tile_log is not None:
+        _tile_log.append((M, N, K, load().ada_debug_last_tile()))
 
 
 def attention(qkv: torch.Tensor, out: torch.Tensor, batch: int, n_tokens: int, heads: int):
@@ -282,6 +293,39 @@ def depth_eval(pred, gt, mask=None, scale_shift=None, clip=None) -> torch.Tensor
                                      _dev(scale_shift, "scale_shift", torch.float32) if scale_shift is not None else None,
                                      lo, hi, _dev(sums, "sums", torch.float64), _stream()), "ada_depth_eval_fwd")
     return sums
+
+
+# --- tuning / diagnostic hooks (include/ada_hip.h, last section) ---------------------------------
+TILE_NAMES = {0: "256x32", 1: "128x64", 2: "256x128", 3: "256x256", 4: "128x128", 5: "128x256x32", 7: "512x128"}
+
+
+_tile_log = None
+
+
+def set_tile_log(log):
+    """log: a list that receives (M, N, K, tile code) for every ada_igemm launch, or None to stop recording."""
+    global _tile_log
+    _tile_log = log
+
+
+def debug_set_tile(cfg: int = -1):
+    load().ada_debug_set_tile(int(cfg))
+
+
+def debug_set_variant(v: int = 8):
+    load().ada_debug_set_variant(int(v))
+
+
+def debug_set_group(g: int = 0):
+    load().ada_debug_set_group(int(g))
+
+
+def debug_last_tile() -> int:
+    return int(load().ada_debug_last_tile())
+
+
+def debug_set_attention_variant(v: int = 0):
+    load().ada_debug_set_attention_variant(int(v))
 
 
 def selftest() -> int:

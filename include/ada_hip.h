@@ -9,8 +9,11 @@
  *
  * Conventions
  *  - plain C, raw device pointers, explicit sizes/strides; no torch types.
- *  - the caller owns every buffer (inputs, outputs, workspaces); the library allocates nothing
- *    and keeps no global state besides a thread-local last-error string.
+ *  - the caller owns every buffer (inputs, outputs, workspaces); the library allocates nothing.
+ *    State kept by the library: a thread-local last-error string, a thread-local "last tile" code,
+ *    and the process-global tuning switches of the ada_debug_* hooks at the end of this header
+ *    (defaults = the shipped configuration; they select between kernels that all compute the same
+ *    result, so a caller that never touches them sees a stateless library).
  *  - every launcher is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant,
  *    and returns 0 on success or a negative ADA_E* code; it never throws or exits.
  *  - "op" = the contraction-operand type the library was built for: IEEE fp16 by default
@@ -237,6 +240,31 @@ int ada_blend_fwd(const float* amodal, const float* base, const float* mask, int
  * kernels assume against a scalar computation on the device.  Returns 0 when they hold,
  * a positive bit mask of failed probes otherwise.  scratch: >= 1 MiB of device memory. */
 int ada_selftest(void* scratch, int64_t scratch_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Tuning / diagnostic hooks.  Process-global switches used by the test-suite (to run every tile
+ * configuration and both main loops of ada_igemm against the same references), by tools/ (A/B
+ * timing) and by bench.py (to report which kernel ran).  They never change results beyond fp32
+ * summation order.  The environment variables ADA_IGEMM_TILE / _VARIANT / _GROUP / _SHORTK preset
+ * the same switches once, at the first ada_igemm call.
+ *   ada_debug_set_tile(cfg)      force the ada_igemm tile: 0 256x32, 1 128x64, 2 256x128, 3 256x256,
+ *                                4 128x128, 5 128x256x32, 7 512x128; -1 = heuristic (default)
+ *   ada_debug_set_variant(v)     main loop of the 256x256 tile: 8 = phased ping-pong loop (default);
+ *                                0/1/2/4 = single-barrier loop with its copy-stagger flavours
+ *   ada_debug_set_group(g)       force the column-group width of the tile order (0 = traffic model)
+ *   ada_debug_last_tile()        tile code of the calling thread's most recent ada_igemm launch
+ *                                (+100 when the phased main loop ran), -1 before the first launch
+ *   ada_debug_set_timestamps(p)  device buffer of 8 x u64 per workgroup receiving s_memtime stamps
+ *                                of the single-barrier loop, or NULL (default)
+ *   ada_debug_set_attention_variant(v)  0 = 8-wave ping-pong kernel with static priority (default),
+ *                                1 = the same without s_setprio, 3 = the 4-wave round-1 kernel
+ * ---------------------------------------------------------------------------------------- */
+void ada_debug_set_tile(int cfg);
+void ada_debug_set_variant(int v);
+void ada_debug_set_group(int g);
+int ada_debug_last_tile(void);
+void ada_debug_set_timestamps(void* dev_buf);
+void ada_debug_set_attention_variant(int v);
 
 #ifdef __cplusplus
 }

@@ -56,8 +56,12 @@ def synth_state_dict(model, meta=None, seed=0):
     return sd
 
 
-def case_inputs(case, seed=0):
-    x, grgb, mask, obs = make_inputs(case["B"], case["H"], case["W"], seed)
+def case_inputs(case, seed=None):
+    """Inputs of a fixture case: make_inputs(B, H, W, seed), restricted to case["take"] when present."""
+    x, grgb, mask, obs = make_inputs(case["B"], case["H"], case["W"], case.get("seed", 0) if seed is None else seed)
+    if "take" in case:
+        idx = torch.tensor(case["take"])
+        x, grgb, mask, obs = x[idx], grgb[idx], mask[idx], obs[idx]
     if case["kind"] == "raw":
         x = (x - torch.tensor(PIXEL_MEAN).view(-1, 1, 1)) / torch.tensor(PIXEL_STD).view(-1, 1, 1)
     return x, grgb, mask, obs

@@ -405,3 +405,206 @@ def test_patchify_split_precision(hip):
     hip.igemm(M=B * 6, N=64, K=3 * seg, A=out, lda=3 * seg, W=Wcat, out_f32=y, ldo_f32=64)
     err = (y.cpu() - ref @ w.T).abs().max()
     assert float(err) < (2e-5 if op == torch.float16 else 2e-3), float(err)
+
+
+# =====================================================================================================================
+# Every tile configuration x every epilogue: the heuristic of ada_igemm picks the 256x256 tile only
+# for problems with hundreds of tiles, so the small shapes above never reach the kernel the benchmark spends 70 % of its
+# time in.  These tests force each tile (ada_debug_set_tile) and both main loops of the 256x256 tile
+# (ada_debug_set_variant: 8 = phased ping-pong loop, 4 = single-barrier loop) on problems that span >= 3 tile rows, end in
+# a ragged tile, and (for the wide ones) engage the column-group tile order.
+# =====================================================================================================================
+TILE_CASES = [(0, 8), (1, 8), (2, 8), (3, 8), (3, 4), (4, 8), (7, 8)]   # (tile cfg, main-loop variant)
+
+
+@pytest.fixture
+def forced_tile(hip):
+    def force(cfg, variant):
+        hip.debug_set_tile(cfg)
+        hip.debug_set_variant(variant)
+    yield force
+    hip.debug_set_tile(-1)
+    hip.debug_set_variant(8)
+    hip.debug_set_group(0)
+
+
+def _check_tile(hip, cfg, variant):
+    code = hip.debug_last_tile()
+    assert code % 100 == cfg, f"forced tile {cfg} but the launch used {code}"
+    if cfg == 3:
+        assert (code >= 100) == (variant >= 8), f"variant {variant} but tile code {code}"
+
+
+@pytest.mark.parametrize("cfg,variant", TILE_CASES)
+@pytest.mark.parametrize("epi", ["std_f32_res", "gelu", "gamma_op", "relu_op_and_f32", "plain_op"])
+def test_igemm_forced_tile_epilogues(hip, forced_tile, cfg, variant, epi):
+    op = _op(hip)
+    M, N, K = 3 * 256 + 77, 2 * 256 + 64, 320     # 4 ragged tile rows of 256, partial last N tile, odd number of k-tiles (5)
+    A = _rand(M, K, seed=201).to(op).to(DEV)
+    W = _rand(N, K, scale=K ** -0.5, seed=202).to(op).to(DEV)
+    b, g = _rand(N, seed=203).to(DEV), (_rand(N, seed=204) * 0.5 + 1).to(DEV)
+    lin = A.float().cpu() @ W.float().cpu().T + b.cpu()
+    forced_tile(cfg, variant)
+    loose = dict(atol=2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3)
+    if epi == "std_f32_res":
+        x = _rand(M, N, seed=205).to(DEV)
+        ref = x.cpu() + lin * g.cpu()
+        hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=W, bias=b, gamma=g, res=x, ldr=N, flags=hip.EP_BIAS | hip.EP_GAMMA | hip.EP_RESIDUAL, out_f32=x, ldo_f32=N)
+        _check_tile(hip, cfg, variant)
+        _close(x, ref, 3e-4, what=f"tile {cfg}/{variant} ls+res")
+    elif epi == "gelu":
+        out = torch.zeros(M, N, dtype=op, device=DEV)
+        hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=W, bias=b, flags=hip.EP_BIAS | hip.EP_GELU, out_op=out, ldo_op=N)
+        _check_tile(hip, cfg, variant)
+        _close(out, F.gelu(lin), what=f"tile {cfg}/{variant} gelu", **loose)
+    elif epi == "gamma_op":
+        out = torch.zeros(M, N, dtype=op, device=DEV)
+        hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=W, bias=b, gamma=g, flags=hip.EP_BIAS | hip.EP_GAMMA, out_op=out, ldo_op=N)
+        _check_tile(hip, cfg, variant)
+        _close(out, lin * g.cpu(), what=f"tile {cfg}/{variant} gamma", **loose)
+    elif epi == "relu_op_and_f32":
+        of = torch.zeros(M, N, device=DEV)
+        oo = torch.zeros(M, N, dtype=op, device=DEV)
+        hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=W, bias=b, flags=hip.EP_BIAS | hip.EP_RELU_OP, out_f32=of, ldo_f32=N, out_op=oo, ldo_op=N)
+        _check_tile(hip, cfg, variant)
+        _close(of, lin, 3e-4, what=f"tile {cfg}/{variant} f32")
+        _close(oo, lin.clamp_min(0), what=f"tile {cfg}/{variant} relu op", **loose)
+    else:
+        out = torch.zeros(M, N, dtype=op, device=DEV)
+        hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=W, out_op=out, ldo_op=N)
+        _check_tile(hip, cfg, variant)
+        _close(out, lin - b.cpu(), what=f"tile {cfg}/{variant} plain", **loose)
+
+
+@pytest.mark.parametrize("cfg,variant", [(3, 8), (3, 4), (2, 8), (4, 8)])
+def test_igemm_forced_tile_column_groups_long_k(hip, forced_tile, cfg, variant):
+    """N = 2304 (9 column tiles of 256) and K = 4096: the weight panel exceeds the L2 model's budget so the launcher walks
+    the tiles in column groups (group_n < tiles_n); also run with the group width forced to 2 and to 1."""
+    op = _op(hip)
+    M, N, K = 1100, 2304, 4096
+    A = _rand(M, K, seed=211).to(op).to(DEV)
+    W = _rand(N, K, scale=K ** -0.5, seed=212).to(op).to(DEV)
+    b = _rand(N, seed=213).to(DEV)
+    ref = A.float().cpu() @ W.float().cpu().T + b.cpu()
+    forced_tile(cfg, variant)
+    for group in (0, 2, 1):
+        hip.debug_set_group(group)
+        out = torch.full((M, N), float("nan"), device=DEV)
+        hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=W, bias=b, flags=hip.EP_BIAS, out_f32=out, ldo_f32=N)
+        _check_tile(hip, cfg, variant)
+        _close(out, ref, 5e-4, what=f"tile {cfg}/{variant} group {group}")
+
+
+@pytest.mark.parametrize("cfg,variant", [(3, 8), (3, 4), (4, 8), (2, 8), (1, 8)])
+def test_igemm_forced_tile_conv3x3_pad_residual(hip, forced_tile, cfg, variant):
+    """3x3 implicit GEMM (9 taps x 2 k-tiles), stride 1, fp32 + residual and ReLU'd zero-bordered NHWC outputs."""
+    op = _op(hip)
+    B, C, H, W_ = 2, 128, 23, 31          # M = 1426: 6 tile rows of 256 with a ragged end
+    x = _rand(B, C, H, W_, seed=221).to(op).float()
+    w = (_rand(C, C, 3, 3, seed=222) * (9 * C) ** -0.5).to(op).float()
+    b = _rand(C, seed=223)
+    res = _rand(B * H * W_, C, seed=224)
+    out_f = torch.zeros(B * H * W_, C, device=DEV)
+    out_p = torch.zeros(B, H + 2, W_ + 2, C, dtype=op, device=DEV)
+    forced_tile(cfg, variant)
+    hip.igemm(M=B * H * W_, N=C, K=9 * C, A=_pad_nhwc(x, C, op).to(DEV), lda=C, W=_pack3(w, C, op).to(DEV), a_mode=hip.A_CONV3,
+              conv=(H, W_, H + 2, W_ + 2, 1), bias=b.to(DEV), res=res.to(DEV), ldr=C, flags=hip.EP_BIAS | hip.EP_RESIDUAL | hip.EP_RELU_OP,
+              out_f32=out_f, ldo_f32=C, out_op=out_p, ldo_op=C, map_op=hip.MAP_PAD, map_h=H, map_w=W_)
+    _check_tile(hip, cfg, variant)
+    ref = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(-1, C) + res
+    _close(out_f, ref, 3e-4, what=f"tile {cfg}/{variant} conv f32")
+    _close(out_p[:, 1:-1, 1:-1].reshape(-1, C), ref.clamp_min(0), 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="conv relu padded")
+    border = out_p.clone()
+    border[:, 1:-1, 1:-1] = 0
+    assert float(border.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg,variant", [(3, 8), (3, 4), (4, 8)])
+def test_igemm_forced_tile_shuffle_and_swiglu(hip, forced_tile, cfg, variant):
+    op = _op(hip)
+    # ConvTranspose2d k = s = 2 as GEMM + pixel shuffle: N = 4 * 256 = 1024
+    s_, C, Ci, B, H, W_ = 2, 256, 128, 2, 19, 23
+    x = _rand(B, Ci, H, W_, seed=231).to(op).float()
+    w = (_rand(Ci, C, s_, s_, seed=232) * Ci ** -0.5).to(op).float()
+    b = _rand(C, seed=233)
+    A = x.permute(0, 2, 3, 1).reshape(-1, Ci).to(op).contiguous()
+    Wp = w.permute(2, 3, 1, 0).reshape(s_ * s_ * C, Ci).to(op).contiguous()
+    out = torch.zeros(B, s_ * H + 2, s_ * W_ + 2, C, dtype=op, device=DEV)
+    forced_tile(cfg, variant)
+    hip.igemm(M=B * H * W_, N=s_ * s_ * C, K=Ci, A=A.to(DEV), lda=Ci, W=Wp.to(DEV), bias=b.repeat(s_ * s_).to(DEV), flags=hip.EP_BIAS,
+              out_op=out, ldo_op=C, map_op=hip.MAP_SHUFFLE, map_h=H, map_w=W_, shuffle_s=s_, shuffle_c=C)
+    _check_tile(hip, cfg, variant)
+    ref = F.conv_transpose2d(x, w, b, stride=s_).permute(0, 2, 3, 1)
+    _close(out[:, 1:-1, 1:-1], ref, 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what=f"tile {cfg}/{variant} convT")
+    # SwiGLU (x1 | x2 interleaved in 32-column groups)
+    M, K, Hd = 900, 192, 512
+    A2 = _rand(M, K, seed=234).to(op).to(DEV)
+    w12 = (_rand(2 * Hd, K, seed=235) * K ** -0.5).to(op)
+    b12 = _rand(2 * Hd, seed=236)
+    idx = torch.arange(Hd).reshape(-1, 32)
+    order = torch.stack([idx, idx + Hd], dim=1).reshape(-1)
+    o2 = torch.zeros(M, Hd, dtype=op, device=DEV)
+    hip.igemm(M=M, N=2 * Hd, K=K, A=A2, lda=K, W=w12[order].contiguous().to(DEV), bias=b12[order].contiguous().to(DEV),
+              flags=hip.EP_BIAS | hip.EP_SWIGLU, out_op=o2, ldo_op=Hd)
+    _check_tile(hip, cfg, variant)
+    x12 = A2.float().cpu() @ w12.float().T + b12
+    _close(o2, F.silu(x12[:, :Hd]) * x12[:, Hd:], 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what=f"tile {cfg}/{variant} swiglu")
+
+
+@pytest.mark.parametrize("variant", [0, 1, 3])
+@pytest.mark.parametrize("B,N,heads", [(2, 1370, 2), (1, 64, 1), (1, 65, 3), (1, 1, 1), (3, 200, 6), (1, 129, 1), (1, 1409, 1), (1, 5330, 1)])
+def test_attention_variants(hip, variant, B, N, heads):
+    """Every attention kernel (0: 8-wave ping-pong + static priority, 1: without priority, 3: the round-1 4-wave kernel) on
+    sequence lengths that exercise: one tile only (half 1 idle), an odd tile count, a single valid key in the last tile, a
+    query block with inactive waves, and the ViT-G 1022^2 length (N = 5330)."""
+    op = _op(hip)
+    D = heads * 64
+    qkv = _rand(B * N, 3 * D, seed=33).to(op)
+    qkv[:, :D] *= 0.125 * LOG2E
+    qkv = qkv.to(op)
+    out = torch.full((B * N, D), float("nan"), dtype=op, device=DEV)
+    hip.debug_set_attention_variant(variant)
+    try:
+        hip.attention(qkv.to(DEV), out, B, N, heads)
+    finally:
+        hip.debug_set_attention_variant(0)
+    t = qkv.float().reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    p = ((t[0] @ t[1].transpose(-2, -1)) / LOG2E).softmax(-1)
+    ref = (p @ t[2]).transpose(1, 2).reshape(B * N, D)
+    _close(out, ref, 2e-3, rtol=1e-2 if op == torch.bfloat16 else 3e-3, what=f"attention variant {variant}")
+
+
+@pytest.mark.parametrize("variant", [0, 3])
+@pytest.mark.parametrize("spike_key", [250, 200, 5])
+def test_attention_variants_force_online_rescale(hip, variant, spike_key):
+    """A dominating key in a late tile of either key half (tile 3 = odd half, tile 3 again via key 200, tile 0): the running
+    max of that half must jump, rescale its O and l, and the merge of the two halves must weight them correctly."""
+    op = _op(hip)
+    N = 300
+    qkv = _rand(N, 192, seed=34) * 0.3
+    qkv[:, 64:128][spike_key] = qkv[:, :64][7] * 40.0
+    qkv = qkv.to(op)
+    out = torch.zeros(N, 64, dtype=op, device=DEV)
+    hip.debug_set_attention_variant(variant)
+    try:
+        hip.attention(qkv.to(DEV), out, 1, N, 1)
+    finally:
+        hip.debug_set_attention_variant(0)
+    t = qkv.float()
+    p = ((t[:, :64] @ t[:, 64:128].T) / LOG2E).softmax(-1)
+    _close(out, p @ t[:, 128:], 2e-3, rtol=1e-2 if op == torch.bfloat16 else 3e-3, what="attention rescale")
+
+
+def test_attention_last_batch_does_not_read_past_the_buffer(hip):
+    """The ping-pong kernel runs its copies two tiles ahead of the sequence end and relies on the buffer bounds check to
+    zero-fill them: the qkv tensor here ends exactly at the end of an allocation-sized block of its own."""
+    op = _op(hip)
+    B, N, heads = 2, 77, 1
+    qkv = (_rand(B * N, 192, seed=35)).to(op).to(DEV).clone()
+    out = torch.zeros(B * N, 64, dtype=op, device=DEV)
+    hip.attention(qkv, out, B, N, heads)
+    torch.cuda.synchronize()
+    t = qkv.float().cpu().reshape(B, N, 3, 1, 64).permute(2, 0, 3, 1, 4)
+    p = ((t[0] @ t[1].transpose(-2, -1)) / LOG2E).softmax(-1)
+    ref = (p @ t[2]).transpose(1, 2).reshape(B * N, 64)
+    _close(out, ref, 2e-3, rtol=1e-2 if op == torch.bfloat16 else 3e-3, what="attention tail batch")

@@ -1,24 +1,43 @@
 """CPU: the oracle restatement reproduces the REAL reference's outputs stored in tests/golden/ (generated
-by oracle/make_golden.py from /root/reference).  This is what pins the oracle; it runs anywhere."""
+by oracle/make_golden.py from /root/reference).  This is what pins the oracle; it runs anywhere.
+
+Cost control (the whole CPU suite has to stay within a few minutes): the batch-8 / batch-32 fixtures replay ONE image
+of the batch (the model is batch-invariant; reference measured 1.2e-7), and the ViT-G 1022x1022 fixture (two minutes
+of CPU per forward) is replayed only when ADA_SLOW_TESTS=1 -- its oracle-vs-reference agreement (max abs 0.0) was
+asserted by oracle/make_golden.py when the fixture was generated and is recorded in the fixture's metadata."""
+import os
+
 import pytest
 import torch
 
 from _cases import case_inputs, golden_names, load_golden, oracle_forward, schema_state_dict
 
-FAST = [n for n in golden_names() if n not in ("vitl_518", "vitb_518", "raw_vitg_224")]
-SLOW = [n for n in golden_names() if n in ("vitl_518", "vitb_518", "raw_vitg_224")]
+SLOW_ONLY = ("raw_vitg_1022",)
+ORDER = sorted(golden_names(), key=lambda n: ("vitl" in n or "vitg" in n, n))
 
 
-@pytest.mark.parametrize("name", FAST + SLOW)
+@pytest.mark.parametrize("name", ORDER)
 def test_oracle_matches_reference_golden(name):
+    if name in SLOW_ONLY and not os.environ.get("ADA_SLOW_TESTS"):
+        gold, meta = load_golden(name)
+        assert meta["oracle_vs_reference_maxabs"] <= 1e-6      # recorded when the fixture was generated
+        pytest.skip("two minutes of CPU per forward: set ADA_SLOW_TESTS=1 to replay")
     gold, meta = load_golden(name)
     case = meta["case"]
     sd = schema_state_dict(case, meta)         # reference key/shape schema fixture + deterministic fill
+    n_img = gold.shape[0]
+    pick = None
+    if n_img > 2 or "take" in case:            # big batches: replay one image of the batch
+        pick = n_img - 1
+        take = case["take"][pick] if "take" in case else pick
+        case = dict(case, take=[take])
+        gold = gold[pick:pick + 1]
     x, grgb, mask, obs = case_inputs(case)
     out = oracle_forward(sd, case, x, grgb, mask, obs)
-    assert list(out.shape) == meta["out_shape"]
+    if pick is None:
+        assert list(out.shape) == meta["out_shape"]
+        assert abs(float(out.mean()) - meta["out_mean"]) < 1e-5
     st = case["stride"]
     sub = out[..., ::st, ::st]
-    # same torch build => bit-identical in practice; allow a few ulps for other CPU kernels / thread counts
+    # same torch build => bit-identical in practice; allow a few ulps for other CPU kernels / thread counts / batch sizes
     assert torch.allclose(sub, gold, atol=2e-5, rtol=1e-5), float((sub - gold).abs().max())
-    assert abs(float(out.mean()) - meta["out_mean"]) < 1e-5

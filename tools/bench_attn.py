@@ -21,6 +21,7 @@ if os.environ.get("ZERO"):
     qkv.zero_()
 out = torch.empty(B * N, D, dtype=op, device="cuda")
 reps = int(os.environ.get("REPS", 10))
+H.debug_set_attention_variant(int(os.environ.get("VARIANT", 0)))
 for _ in range(2):
     H.attention(qkv, out, B, N, heads)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,4 +32,4 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(f"attention B={B} N={N} heads={heads}: {ms * 1e3:.1f} us  {4.0 * B * heads * 64 * N * N / ms / 1e9:.1f} TFLOP/s")
+print(f"variant={os.environ.get('VARIANT', 0)} attention B={B} N={N} heads={heads}: {ms * 1e3:.1f} us  {4.0 * B * heads * 64 * N * N / ms / 1e9:.1f} TFLOP/s")

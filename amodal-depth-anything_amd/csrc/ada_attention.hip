@@ -19,6 +19,8 @@
 //   LDS reads are inline asm with hand-placed s_waitcnt: all 8 K reads are issued ahead of the QK^T MFMAs and all 16
 //   V transpose reads BEFORE the softmax so they land behind it (hipcc sinks each ds_read next to its MFMA otherwise).
 //   N = 1370 is not a multiple of 64: the last tile masks keys >= N to -inf.
+#include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 #include "ada_common.h"
 
@@ -44,12 +46,42 @@ ADA_DEV void half_exchange(float x, float& lo, float& hi_) {
     hi_ = __builtin_bit_cast(float, b);
 }
 
+// Row sum of P.  ADA_ROWSUM 0: v_dot2c_f32_f16 on the packed pair (round 1); 1: two fp32 adds of the unrounded exponentials;
+// 2: v_pk_add_f16 into a packed fp16 accumulator (per tile), folded into the fp32 sum once per tile.  Beside an MFMA the dot2c
+// form costs ~13 ns per slot, the two adds ~5, the packed add ~1 (tools/ubench/softmax_slot.hip, profiles/r02_a_softmax_slot_ubench.txt).
+#ifndef ADA_ROWSUM
+#define ADA_ROWSUM 1
+#endif
+struct RowSum {
+    float a0 = 0.0f, a1 = 0.0f;
+    opx2 h = {(op_t)0.0f, (op_t)0.0f};
+    ADA_DEV void add(float e0, float e1, opx2 pp, bool odd);
+    ADA_DEV float total() const {
+#if ADA_ROWSUM == 2
+        return (float)h[0] + (float)h[1];
+#else
+        return a0 + a1;
+#endif
+    }
+};
 ADA_DEV float dot2_acc(opx2 p, float acc) {
 #ifdef ADA_OPERAND_BF16
     return acc + (float)p[0] + (float)p[1];
 #else
     const opx2 ones = {(op_t)1.0f, (op_t)1.0f};
     return __builtin_amdgcn_fdot2(p, ones, acc, false);
+#endif
+}
+
+ADA_DEV void RowSum::add(float e0, float e1, opx2 pp, bool odd) {
+#if ADA_ROWSUM == 0
+    if (odd) a1 = dot2_acc(pp, a1);
+    else a0 = dot2_acc(pp, a0);
+#elif ADA_ROWSUM == 1
+    a0 += e0;
+    a1 += e1;
+#else
+    h = h + pp;
 #endif
 }
 
@@ -221,21 +253,21 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_v3(const op_t* __rest
                 for (int r = 0; r < 16; ++r) sT[kb][r] -= delta;
         }
         opx8 pf[2][2];
-        float ps0 = 0.0f, ps1 = 0.0f;
+        RowSum rs;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 opx2 pp;
-                pp[0] = (op_t)__builtin_amdgcn_exp2f(sT[kb][r]);
-                pp[1] = (op_t)__builtin_amdgcn_exp2f(sT[kb][r + 1]);
+                const float e0 = __builtin_amdgcn_exp2f(sT[kb][r]), e1 = __builtin_amdgcn_exp2f(sT[kb][r + 1]);
+                pp[0] = (op_t)e0;
+                pp[1] = (op_t)e1;
                 pf[kb][r >> 3][r & 7] = pp[0];
                 pf[kb][r >> 3][(r & 7) + 1] = pp[1];
-                if (r & 2) ps1 = dot2_acc(pp, ps1);
-                else ps0 = dot2_acc(pp, ps0);
+                rs.add(e0, e1, pp, (r & 2) != 0);
             }
         }
-        l_run += ps0 + ps1;
+        l_run += rs.total();
 
         // ---- O^T += V^T P^T --------------------------------------------------------------------
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -306,9 +338,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_v3(const op_t* __rest
 // =====================================================================================================================
 constexpr int PP_HALF_BYTES = 2 * K_TILE + 2 * V_TILE;   // 32 KB: [K0 | K1 | V0 | V1]
 
-template <bool PRIO>
+// ABL (timing ablations only, results are garbage): 1 = no MFMAs, 2 = no softmax arithmetic, 3 = no fragment reads, 4 = no copies
+template <bool PRIO, bool PROF = false, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void attention_kernel_pp(const op_t* __restrict__ qkv, op_t* __restrict__ out,
-                                                              int n_tok, int heads, int nqb, int n_bh) {
+                                                              int n_tok, int heads, int nqb, int n_bh, unsigned long long* prof = nullptr) {
     __shared__ __attribute__((aligned(16))) char smem[2 * PP_HALF_BYTES];
 
     const int tid = threadIdx.x;
@@ -412,13 +445,26 @@ __global__ __launch_bounds__(512, 2) void attention_kernel_pp(const op_t* __rest
     if (kh == 1) __builtin_amdgcn_s_barrier();   // half 1 runs one interval behind half 0
     if (PRIO && kh == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the younger half (T5 static form)
 
+    // PROF: s_memtime stamps per wave -- [0] matrix interval up to the last MFMA issue, [1] vmcnt wait, [2] barrier wait,
+    // [3] softmax interval incl. the fragment-read wait, [4] barrier wait
+    unsigned long long tp[5] = {0, 0, 0, 0, 0}, t_prev = 0;
+    auto stamp = [&](int k) {
+        if constexpr (PROF) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            tp[k] += t - t_prev;
+            t_prev = t;
+        }
+    };
+    if constexpr (PROF) t_prev = __builtin_amdgcn_s_memtime();
     auto m_interval = [&](auto parity, int j) {
         constexpr int P = decltype(parity)::value;     // j & 1
         const int tile = 2 * j + kh;
+        if (ABL != 4) {
         stage_k(P, tile + 4);                // K(j+2) -> K buffer j&1 (last read in the previous softmax interval)
         stage_v(P ^ 1, tile + 2);            // V(j+1) -> V buffer (j+1)&1
+        }
         __builtin_amdgcn_sched_barrier(0);
-        if (wave_active) {
+        if (wave_active && ABL != 1) {
             if (j > 0 && tile - 2 < nt) {    // O^T += V(j-1)^T P(j-1)^T
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -444,8 +490,11 @@ __global__ __launch_bounds__(512, 2) void attention_kernel_pp(const op_t* __rest
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the copies issued one interval ago (K(j+1), V(j)) have landed
+        stamp(0);
+        if (ABL != 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the copies issued one interval ago (K(j+1), V(j)) have landed
+        stamp(1);
         __builtin_amdgcn_s_barrier();
+        stamp(2);
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -453,6 +502,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel_pp(const op_t* __rest
         constexpr int P = decltype(parity)::value;
         const int tile = 2 * j + kh;
         // operands of the NEXT matrix interval: V(j) (transpose reads) and K(j+1); they land behind the softmax below
+        if (ABL != 3) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -467,7 +517,8 @@ __global__ __launch_bounds__(512, 2) void attention_kernel_pp(const op_t* __rest
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[kb][s]) : "v"(kofs[s]), "i"((P ^ 1) * K_TILE + kb * 32 * ROWB));
-        if (wave_active && tile < nt) {
+        }
+        if (wave_active && tile < nt && ABL != 2) {
             if (tile == nt - 1) {            // mask keys beyond the sequence (wave-uniform branch)
                 const int kv0 = tile * KVB;
 #pragma unroll
@@ -504,28 +555,30 @@ __global__ __launch_bounds__(512, 2) void attention_kernel_pp(const op_t* __rest
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sT[kb][r] -= delta;
             }
-            float ps0 = 0.0f, ps1 = 0.0f;
+            RowSum rs;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     opx2 pp;
-                    pp[0] = (op_t)__builtin_amdgcn_exp2f(sT[kb][r]);
-                    pp[1] = (op_t)__builtin_amdgcn_exp2f(sT[kb][r + 1]);
+                    const float e0 = __builtin_amdgcn_exp2f(sT[kb][r]), e1 = __builtin_amdgcn_exp2f(sT[kb][r + 1]);
+                    pp[0] = (op_t)e0;
+                    pp[1] = (op_t)e1;
                     pf[kb][r >> 3][r & 7] = pp[0];
                     pf[kb][r >> 3][(r & 7) + 1] = pp[1];
-                    if (r & 2) ps1 = dot2_acc(pp, ps1);
-                    else ps0 = dot2_acc(pp, ps0);
+                    rs.add(e0, e1, pp, (r & 2) != 0);
                 }
             }
-            l_run += ps0 + ps1;
+            l_run += rs.total();
         }
         // the fragment reads above must have returned before any wave of this half refills the buffers they came from
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]));
         asm volatile("" : "+v"(vlo[0][0][0]), "+v"(vlo[0][0][1]), "+v"(vlo[0][1][0]), "+v"(vlo[0][1][1]), "+v"(vlo[1][0][0]), "+v"(vlo[1][0][1]), "+v"(vlo[1][1][0]), "+v"(vlo[1][1][1]));
         asm volatile("" : "+v"(vhi[0][0][0]), "+v"(vhi[0][0][1]), "+v"(vhi[0][1][0]), "+v"(vhi[0][1][1]), "+v"(vhi[1][0][0]), "+v"(vhi[1][0][1]), "+v"(vhi[1][1][0]), "+v"(vhi[1][1][1]));
         __builtin_amdgcn_sched_barrier(0);
+        stamp(3);
         __builtin_amdgcn_s_barrier();
+        stamp(4);
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -551,6 +604,14 @@ __global__ __launch_bounds__(512, 2) void attention_kernel_pp(const op_t* __rest
                     vf[4] = hi4[0]; vf[5] = hi4[1]; vf[6] = hi4[2]; vf[7] = hi4[3];
                     o[db] = mfma32(vf, pf[kb][s], o[db]);
                 }
+    }
+    if constexpr (PROF) {
+        if (lane == 0 && prof) {
+            unsigned long long* d = prof + ((long)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) d[k] = tp[k];
+            d[5] = (unsigned long long)jmax;
+        }
     }
     if (PRIO && kh == 1) __builtin_amdgcn_s_setprio(0);
     if (kh == 0) __builtin_amdgcn_s_barrier();       // balances half 1's extra barrier
@@ -593,12 +654,319 @@ __global__ __launch_bounds__(512, 2) void attention_kernel_pp(const op_t* __rest
     }
 }
 
+
+// =====================================================================================================================
+// attention_kernel_mix -- 4 waves x 32 query rows, two independent workgroups per CU (<= 256 VGPRs), the softmax VALU stream
+// of tile j interleaved INSIDE each wave with the MFMAs of P(j-1) V(j-1) and of S(j+1) = K(j+1) Q^T.
+//
+// Why (measured, profiles/r02_*): at head_dim 64 a 64-key tile costs a wave 16 MFMAs (512 cycles of the SIMD's matrix pipe) but
+// ~92 VALU instructions, and ONE wave issues a VALU instruction only every ~5.7 cycles (v_exp_f32: 8.5; tools/ubench/valu_rates.hip:
+// two waves together reach 2.3-4.6).  A softmax phase that runs by itself therefore takes ~1100 cycles however well the partner
+// wave's MFMAs are hidden behind it -- the ping-pong kernel above (809-cycle matrix interval beside a 1100-cycle softmax interval) and
+// the round-1 kernel both sit at that bound.  Here every MFMA of a wave is followed by <= 8 independent VALU/LDS instructions of the
+// same wave, so a wave's instruction stream keeps both pipes busy by itself and the second wave on the SIMD fills the gaps:
+//
+//   iteration j:   A   row max of S(j), rescale decision (rare path rescales O, P(j-1), l, S(j))
+//                  B   8 MFMAs  O += V(j-1)^T P(j-1)   | exp2 / cvt / row-sum of S(j) -> P(j) | reads K(j+1) fragments
+//                  C   8 MFMAs  S(j+1) = K(j+1) Q^T - m | rest of the exp2 stream            | reads V(j) fragments
+//                  D   lgkmcnt(0), vmcnt(0), one barrier (copies of K(j+2), V(j+1) were issued at the top of the iteration)
+//   The order inside B / C is pinned group by group with sched_barrier(0): one MFMA, then its fillers.
+// =====================================================================================================================
+__global__ __launch_bounds__(256, 2) void attention_kernel_mix(const op_t* __restrict__ qkv, op_t* __restrict__ out,
+                                                               int n_tok, int heads, int nqb, int n_bh) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE + 2 * V_TILE];   // [K0 | K1 | V0 | V1]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hi = lane >> 5;
+
+    int bh, qb;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        bh = logical / nqb;
+        qb = logical - bh * nqb;
+    }
+    const int b = bh / heads, h = bh - b * heads;
+    const long D = (long)heads * HD;
+    const long row_stride = 3 * D;
+    const op_t* base = qkv + (long)b * n_tok * row_stride + (long)h * HD;
+
+    const unsigned win_bytes = (unsigned)((long)(n_tok - 1) * row_stride * 2 + HD * 2);   // keys >= n_tok read as zero
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + D), 0, (int)win_bytes, 0x20000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + 2 * D), 0, (int)win_bytes, 0x20000);
+
+    const int q_row = qb * QBLK + wave * 32 + l31;
+    const int q_ld = q_row < n_tok ? q_row : n_tok - 1;
+    const bool wave_active = (qb * QBLK + wave * 32) < n_tok;   // wave-uniform
+    opx8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const opx8*)(base + (long)q_ld * row_stride + 16 * s + 8 * hi);
+
+    const int srow = tid >> 3, sc = tid & 7;
+    const unsigned row_bytes = (unsigned)(row_stride * 2);
+    const unsigned k_voff = (unsigned)srow * row_bytes + (unsigned)((sc ^ ((srow >> 1) & 7)) * 16);
+    const unsigned v_voff = (unsigned)srow * row_bytes + (unsigned)((sc ^ (((srow >> 1) & 1) << 2)) * 16);
+    const unsigned pass_bytes = 32u * row_bytes;
+    char* const my_lds = smem + wave * 1024;
+    auto stage_k = [&](int buf, int tile) {
+        const unsigned so = (unsigned)tile * 2u * pass_bytes;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(my_lds + buf * K_TILE), 16, (int)(k_voff + so), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(my_lds + buf * K_TILE + 4096), 16, (int)(k_voff + so + pass_bytes), 0, 0, 0);
+    };
+    auto stage_v = [&](int buf, int tile) {
+        const unsigned so = (unsigned)tile * 2u * pass_bytes;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(my_lds + 2 * K_TILE + buf * V_TILE), 16, (int)(v_voff + so), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(my_lds + 2 * K_TILE + buf * V_TILE + 4096), 16, (int)(v_voff + so + pass_bytes), 0, 0, 0);
+    };
+
+    f32x16 o[2], negm, sT[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.0f; o[1][r] = 0.0f; negm[r] = 0.0f; }
+    float m_run = 0.0f, l_run = 0.0f;
+    constexpr float RESCALE_THR = 8.0f;
+
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int swz = (l31 >> 1) & 7;
+    unsigned kofs[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kofs[s] = lds0 + l31 * ROWB + (((2 * s + hi) ^ swz) * 16);
+    const int i16 = lane & 15;
+    const int g1 = (lane >> 4) & 1;
+    const int vsw = (i16 >> 3) & 1;
+    const unsigned v_row_part = lds0 + 2 * K_TILE + (4 * hi + (i16 >> 2)) * ROWB + (16 * g1 + 4 * (i16 & 3)) * 2;
+    const unsigned vofs0 = v_row_part + (vsw ? 64u : 0u), vofs1 = v_row_part + (vsw ? 0u : 64u);
+
+    const int nt = (n_tok + KVB - 1) / KVB;
+
+    opx8 kf[2][4];
+    opx8 vf[2][2][2];     // [kb][s][db]: V^T fragment of keys kb*32 + s*16 .. +15, d block db (low half = rows 0-7 of the 16, high = 8-15)
+    opx8 pf[2][2], pn[2][2];   // P(j-1) (consumed by the PV MFMAs) and P(j) (being produced)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pf[kb][s][e] = (op_t)0.0f; vf[kb][s][0][e] = (op_t)0.0f; vf[kb][s][1][e] = (op_t)0.0f; }
+        }
+
+    // one V^T fragment = two transpose reads (rows +0 and +8 of the 16-key step) into the two halves of an opx8
+    auto read_v = [&](auto pbuf, int kb, int s, int db) {
+        constexpr int PB = decltype(pbuf)::value;
+        u32x2 lo, hi2;
+        const unsigned a = db ? vofs1 : vofs0;
+        if (kb == 0 && s == 0) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "i"(PB * V_TILE + (0 * 32 + 0 * 16) * ROWB));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi2) : "v"(a), "i"(PB * V_TILE + (0 * 32 + 0 * 16 + 8) * ROWB));
+        } else if (kb == 0 && s == 1) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "i"(PB * V_TILE + (0 * 32 + 1 * 16) * ROWB));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi2) : "v"(a), "i"(PB * V_TILE + (0 * 32 + 1 * 16 + 8) * ROWB));
+        } else if (kb == 1 && s == 0) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "i"(PB * V_TILE + (1 * 32 + 0 * 16) * ROWB));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi2) : "v"(a), "i"(PB * V_TILE + (1 * 32 + 0 * 16 + 8) * ROWB));
+        } else {
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "i"(PB * V_TILE + (1 * 32 + 1 * 16) * ROWB));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi2) : "v"(a), "i"(PB * V_TILE + (1 * 32 + 1 * 16 + 8) * ROWB));
+        }
+        u32x4 w;
+        w[0] = lo[0]; w[1] = lo[1]; w[2] = hi2[0]; w[3] = hi2[1];
+        vf[kb][s][db] = __builtin_bit_cast(opx8, w);
+    };
+    auto read_k = [&](auto pbuf, int kb, int s) {
+        constexpr int PB = decltype(pbuf)::value;
+        (void)kf; (void)kofs;   // asm operands alone do not make a generic lambda capture (clang 22)
+        if (kb == 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[0][s]) : "v"(kofs[s]), "i"(PB * K_TILE));
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[1][s]) : "v"(kofs[s]), "i"(PB * K_TILE + 32 * ROWB));
+    };
+    RowSum rs;
+    float mx0 = 0.0f;
+    // VALU unit u (0..15): two scores of S(j) -> two P values, packed, summed.  u < 8: key block 0, u >= 8: key block 1
+    auto sm_unit = [&](int u) {
+        const int kb = u >> 3, r = (u & 7) * 2;
+        opx2 pp;
+        const float e0 = __builtin_amdgcn_exp2f(sT[kb][r]), e1 = __builtin_amdgcn_exp2f(sT[kb][r + 1]);
+        pp[0] = (op_t)e0;
+        pp[1] = (op_t)e1;
+        pn[kb][r >> 3][r & 7] = pp[0];
+        pn[kb][r >> 3][(r & 7) + 1] = pp[1];
+        rs.add(e0, e1, pp, (r & 2) != 0);
+    };
+    auto fence = []() { __builtin_amdgcn_sched_barrier(0); };
+
+    // ---- prologue: K(0), V(0), K(1) -> LDS; S(0) -------------------------------------------------
+    stage_k(0, 0);
+    stage_v(0, 0);
+    stage_k(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])::"memory");
+    __syncthreads();
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) read_k(I0{}, kb, s);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    fence();
+    sT[0] = mfma32(kf[0][0], qf[0], negm);
+    sT[1] = mfma32(kf[1][0], qf[0], negm);
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {
+        sT[0] = mfma32(kf[0][s], qf[s], sT[0]);
+        sT[1] = mfma32(kf[1][s], qf[s], sT[1]);
+    }
+    __syncthreads();   // every wave holds its K(0) fragments: K buffer 0 may be refilled
+
+    auto iteration = [&](auto parity, int j) {
+        constexpr int P = decltype(parity)::value;      // j & 1
+        using PB = std::integral_constant<int, P>;
+        using PN = std::integral_constant<int, P ^ 1>;
+        // copies for the next iteration: K(j+2) -> K buffer j&1 (K(j)'s fragments were consumed in iteration j-1),
+        //                                V(j+1) -> V buffer (j+1)&1 (V(j-1)'s fragments were read in iteration j-1)
+        stage_k(P, j + 2);
+        stage_v(P ^ 1, j + 1);
+        fence();
+        if (wave_active) {
+            // ---- A: row max, decision -----------------------------------------------------------
+            if (j == nt - 1) {
+                const int kv0 = j * KVB;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kv0 + kb * 32 + crow32(r, hi) >= n_tok) sT[kb][r] = -INFINITY;
+            }
+            // the maximum over key block 0 (mx0) was taken under the last four MFMAs of the previous iteration
+            if (j == nt - 1 || j == 0) {
+                mx0 = __builtin_fmaxf(sT[0][0], sT[0][1]);
+#pragma unroll
+                for (int r = 2; r < 16; r += 2) mx0 = __builtin_fmaxf(__builtin_fmaxf(mx0, sT[0][r]), sT[0][r + 1]);
+            }
+            float mx1 = __builtin_fmaxf(sT[1][0], sT[1][1]);
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) mx1 = __builtin_fmaxf(__builtin_fmaxf(mx1, sT[1][r]), sT[1][r + 1]);
+            float mx = __builtin_fmaxf(mx0, mx1);
+            {
+                float a, b2;
+                half_exchange(mx, a, b2);
+                mx = __builtin_fmaxf(a, b2);
+            }
+            if (j == 0 || __any(mx > RESCALE_THR)) {
+                const bool mv = (j == 0) || (mx > RESCALE_THR);
+                const float m_new = mv ? m_run + mx : m_run;
+                const float delta = m_new - m_run;
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                const op_t alpha_op = (op_t)alpha;     // alpha <= 1; P(j-1) <= 2^8: no overflow
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[r] = -m_new;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pf[kb][s][e] = pf[kb][s][e] * alpha_op;   // P(j-1) has not entered O yet
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sT[kb][r] -= delta;
+            }
+            rs = RowSum();
+            fence();
+            // ---- B: O += V(j-1)^T P(j-1)^T, interleaved with the first 12 softmax units and the K(j+1) fragment reads ----
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int kb = g >> 2, s = (g >> 1) & 1, db = g & 1;
+                o[db] = mfma32(vf[kb][s][db], pf[kb][s], o[db]);
+                if (g < 4) { sm_unit(2 * g); sm_unit(2 * g + 1); }
+                else sm_unit(4 + g);
+                if (g < 4) { read_k(PN{}, 0, g); read_k(PN{}, 1, g); }
+                fence();
+            }
+            // ---- C: S(j+1) = K(j+1) Q^T - m; key block 0 first (its S(j) registers are dead), the last 4 units beside it ----
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]));
+            fence();
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int kb = g >> 2, s = g & 3;
+                if (s == 0) sT[kb] = mfma32(kf[kb][0], qf[0], negm);
+                else sT[kb] = mfma32(kf[kb][s], qf[s], sT[kb]);
+                if (g < 4) {
+                    sm_unit(12 + g);
+                    read_v(PB{}, g >> 1, g & 1, 0);
+                    read_v(PB{}, g >> 1, g & 1, 1);
+                } else {   // key block 0 of S(j+1) is complete: start on its row maximum
+                    const int r = (g - 4) * 4;
+                    const float t = __builtin_fmaxf(__builtin_fmaxf(sT[0][r], sT[0][r + 1]), __builtin_fmaxf(sT[0][r + 2], sT[0][r + 3]));
+                    mx0 = g == 4 ? t : __builtin_fmaxf(mx0, t);
+                }
+                fence();
+            }
+            l_run += rs.total();
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) pf[kb][s] = pn[kb][s];
+        }
+        // ---- D ----
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0][0]), "+v"(vf[0][0][1]), "+v"(vf[0][1][0]), "+v"(vf[0][1][1]), "+v"(vf[1][0][0]), "+v"(vf[1][0][1]), "+v"(vf[1][1][0]), "+v"(vf[1][1][1]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fence();
+        __builtin_amdgcn_s_barrier();
+        fence();
+    };
+
+    for (int j = 0; j < nt; j += 2) {
+        iteration(I0{}, j);
+        if (j + 1 < nt) iteration(I1{}, j + 1);
+    }
+    // ---- last P V ---------------------------------------------------------------------------------
+    if (wave_active) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int kb = g >> 2, s = (g >> 1) & 1, db = g & 1;
+            o[db] = mfma32(vf[kb][s][db], pf[kb][s], o[db]);
+        }
+    }
+    float l_lo, l_hi;
+    half_exchange(l_run, l_lo, l_hi);
+    const float inv = 1.0f / (l_lo + l_hi);
+    if (q_row < n_tok) {
+        op_t* orow = out + ((long)b * n_tok + q_row) * D + (long)h * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                opx4 v4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = to_op(o[db][g * 4 + e] * inv);
+                *(opx4*)(orow + db * 32 + 8 * g + 4 * hi) = v4;
+            }
+        }
+    }
+}
+
 }  // namespace
 
-static int g_attn_variant = 0;   // 0: ping-pong (default), 1: ping-pong without static priority, 3: round-1 kernel (v3)
+static int g_attn_variant = 5;   // 5: mixed-stream kernel (default); 0: ping-pong, 1: ping-pong without static priority, 2: profiled ping-pong, 3: round-1 kernel (v3)
+static unsigned long long* g_attn_prof = nullptr;
 extern "C" void ada_debug_set_attention_variant(int v) { g_attn_variant = v; }
+extern "C" void ada_debug_set_attention_profile(void* dev_buf) { g_attn_prof = (unsigned long long*)dev_buf; }
 
 extern "C" int ada_attention_fwd(const void* qkv, void* out, int32_t batch, int32_t n_tokens, int32_t heads, void* stream) {
+    static std::once_flag env_once;   // ADA_ATTN_VARIANT presets the kernel choice once (same meaning as ada_debug_set_attention_variant)
+    std::call_once(env_once, []() {
+        const char* e = getenv("ADA_ATTN_VARIANT");
+        if (e) g_attn_variant = atoi(e);
+    });
     ADA_REQUIRE(qkv && out, ADA_EINVAL, "ada_attention_fwd: null pointer");
     ADA_REQUIRE(batch > 0 && n_tokens > 0 && heads > 0, ADA_EINVAL, "ada_attention_fwd: bad shape B=%d N=%d H=%d", batch, n_tokens, heads);
     ADA_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, ADA_EINVAL, "ada_attention_fwd: buffers must be 16-byte aligned");
@@ -609,11 +977,17 @@ extern "C" int ada_attention_fwd(const void* qkv, void* out, int32_t batch, int3
     if (g_attn_variant == 3)
         hipLaunchKernelGGL(attention_kernel_v3, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const op_t*)qkv, (op_t*)out,
                            n_tokens, heads, nqb, batch * heads);
+    else if (g_attn_variant == 5)
+        hipLaunchKernelGGL(attention_kernel_mix, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const op_t*)qkv, (op_t*)out,
+                           n_tokens, heads, nqb, batch * heads);
+    else if (g_attn_variant == 2)
+        hipLaunchKernelGGL((attention_kernel_pp<true, true>), dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, (const op_t*)qkv, (op_t*)out,
+                           n_tokens, heads, nqb, batch * heads, g_attn_prof);
     else if (g_attn_variant == 1)
         hipLaunchKernelGGL(attention_kernel_pp<false>, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, (const op_t*)qkv, (op_t*)out,
-                           n_tokens, heads, nqb, batch * heads);
+                           n_tokens, heads, nqb, batch * heads, (unsigned long long*)nullptr);
     else
         hipLaunchKernelGGL(attention_kernel_pp<true>, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, (const op_t*)qkv, (op_t*)out,
-                           n_tokens, heads, nqb, batch * heads);
+                           n_tokens, heads, nqb, batch * heads, (unsigned long long*)nullptr);
     return ada_check_launch("ada_attention_fwd");
 }

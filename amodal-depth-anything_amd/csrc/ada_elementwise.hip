@@ -6,6 +6,19 @@
 
 namespace {
 
+// operand-typed float4 store; split_seg > 0 writes [hi | lo | hi] column segments (split precision, see ada_igemm_args.split_seg)
+ADA_DEV void store_op4_split(op_t* row, int c, float4 r, int split_seg) {
+    opx4 o;
+    o[0] = to_op(r.x); o[1] = to_op(r.y); o[2] = to_op(r.z); o[3] = to_op(r.w);
+    ((opx4*)row)[c] = o;
+    if (split_seg > 0) {
+        opx4 l;
+        l[0] = to_op(r.x - (float)o[0]); l[1] = to_op(r.y - (float)o[1]); l[2] = to_op(r.z - (float)o[2]); l[3] = to_op(r.w - (float)o[3]);
+        ((opx4*)(row + split_seg))[c] = l;
+        ((opx4*)(row + 2 * split_seg))[c] = o;
+    }
+}
+
 constexpr int LN_MAX_CHUNKS = 6;  // float4 chunks per lane: dim <= 6 * 64 * 4 = 1536
 
 ADA_DEV float wave_sum(float v) {
@@ -40,6 +53,7 @@ struct LnArgs {
     int relu;
     float* out_f32;
     long ld_f32;
+    int split_seg;
 };
 
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
@@ -96,11 +110,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
                 y.z = __builtin_fmaxf(y.z, 0.f); y.w = __builtin_fmaxf(y.w, 0.f);
             }
             if (p.out_f32) ((float4*)(p.out_f32 + (long)ro * p.ld_f32))[c] = y;
-            if (p.out_op) {
-                opx4 o;
-                o[0] = to_op(y.x); o[1] = to_op(y.y); o[2] = to_op(y.z); o[3] = to_op(y.w);
-                ((opx4*)(p.out_op + orow * p.ld_op))[c] = o;
-            }
+            if (p.out_op) store_op4_split(p.out_op + orow * p.ld_op, c, y, p.split_seg);
         }
     }
 }
@@ -173,6 +183,7 @@ struct BilinearArgs {
     op_t* out_op;
     long ld_op;
     int map_op, relu;
+    int split_seg;
     FastDiv dC4, dWo, dHo;
 };
 
@@ -211,13 +222,11 @@ __global__ __launch_bounds__(256) void bilinear_kernel(BilinearArgs p) {
     if (p.out_op) {
         long orow = pix;
         if (p.map_op == ADA_MAP_PAD) orow = ((long)b * (p.ho + 2) + (y + 1)) * (p.wo + 2) + (x + 1);
-        opx4 o;
         if (p.relu) {
             r.x = __builtin_fmaxf(r.x, 0.f); r.y = __builtin_fmaxf(r.y, 0.f);
             r.z = __builtin_fmaxf(r.z, 0.f); r.w = __builtin_fmaxf(r.w, 0.f);
         }
-        o[0] = to_op(r.x); o[1] = to_op(r.y); o[2] = to_op(r.z); o[3] = to_op(r.w);
-        ((opx4*)(p.out_op + orow * p.ld_op))[c] = o;
+        store_op4_split(p.out_op + orow * p.ld_op, c, r, p.split_seg);
     }
 }
 
@@ -289,9 +298,7 @@ __global__ __launch_bounds__(256) void bilinear_tiled_kernel(BilinearArgs p, int
                 r.x = __builtin_fmaxf(r.x, 0.f); r.y = __builtin_fmaxf(r.y, 0.f);
                 r.z = __builtin_fmaxf(r.z, 0.f); r.w = __builtin_fmaxf(r.w, 0.f);
             }
-            opx4 o;
-            o[0] = to_op(r.x); o[1] = to_op(r.y); o[2] = to_op(r.z); o[3] = to_op(r.w);
-            ((opx4*)(p.out_op + orow * p.ld_op))[c] = o;
+            store_op4_split(p.out_op + orow * p.ld_op, c, r, p.split_seg);
         }
     }
 }
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(256) void bilinear_tiled_kernel(BilinearArgs p, int
 
 extern "C" int ada_layernorm_fwd(const float* in, int64_t ld_in, int32_t rows_out, int32_t dim, int32_t group_in, int32_t skip,
                                  const float* weight, const float* bias, float eps, void* out_op, int64_t ld_op, int32_t map_op,
-                                 int32_t map_h, int32_t map_w, int32_t relu, float* out_f32, int64_t ld_f32, void* stream) {
+                                 int32_t map_h, int32_t map_w, int32_t relu, float* out_f32, int64_t ld_f32, int32_t split_seg, void* stream) {
     ADA_REQUIRE(in && weight && bias, ADA_EINVAL, "ada_layernorm_fwd: null pointer");
     ADA_REQUIRE(out_op || out_f32, ADA_EINVAL, "ada_layernorm_fwd: no output buffer");
     ADA_REQUIRE(rows_out > 0 && dim > 0, ADA_EINVAL, "ada_layernorm_fwd: bad shape rows=%d dim=%d", rows_out, dim);
@@ -318,6 +325,8 @@ extern "C" int ada_layernorm_fwd(const float* in, int64_t ld_in, int32_t rows_ou
     p.dMapW = make_fastdiv(map_w > 0 ? map_w : 1);
     p.dMapHW = make_fastdiv(map_h > 0 && map_w > 0 ? map_h * map_w : 1);
     p.relu = relu; p.out_f32 = out_f32; p.ld_f32 = ld_f32;
+    ADA_REQUIRE(split_seg == 0 || (out_op && split_seg >= dim && split_seg % 4 == 0 && ld_op >= 3L * split_seg), ADA_EINVAL, "ada_layernorm_fwd: bad split_seg=%d for dim=%d ld_op=%ld", split_seg, dim, (long)ld_op);
+    p.split_seg = split_seg;
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows_out + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     return ada_check_launch("ada_layernorm_fwd");
 }
@@ -353,7 +362,7 @@ extern "C" int ada_write_cls(float* tokens, int32_t batch, int32_t n_tokens, int
 
 extern "C" int ada_bilinear_fwd(const float* in, int64_t ld_in, int32_t batch, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
                                 int32_t channels, const float* add, int64_t ld_add, float* out_f32, int64_t ld_f32, void* out_op,
-                                int64_t ld_op, int32_t map_op, int32_t relu, void* stream) {
+                                int64_t ld_op, int32_t map_op, int32_t relu, int32_t split_seg, void* stream) {
     ADA_REQUIRE(in && (out_f32 || out_op), ADA_EINVAL, "ada_bilinear_fwd: null pointer");
     ADA_REQUIRE(batch > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0 && channels > 0, ADA_EINVAL, "ada_bilinear_fwd: bad shape");
     ADA_REQUIRE(channels % 4 == 0 && ld_in % 4 == 0 && (!add || ld_add % 4 == 0) && (!out_f32 || ld_f32 % 4 == 0) && (!out_op || ld_op % 4 == 0),
@@ -366,6 +375,8 @@ extern "C" int ada_bilinear_fwd(const float* in, int64_t ld_in, int32_t batch, i
     p.sx = wo > 1 ? (float)(wi - 1) / (float)(wo - 1) : 0.0f;
     p.add = add; p.ld_add = ld_add; p.out_f32 = out_f32; p.ld_f32 = ld_f32; p.out_op = (op_t*)out_op; p.ld_op = ld_op;
     p.map_op = map_op; p.relu = relu;
+    ADA_REQUIRE(split_seg == 0 || (out_op && split_seg >= channels && split_seg % 4 == 0 && ld_op >= 3L * split_seg), ADA_EINVAL, "ada_bilinear_fwd: bad split_seg=%d for %d channels, ld_op=%ld", split_seg, channels, (long)ld_op);
+    p.split_seg = split_seg;
     p.dC4 = make_fastdiv(p.c4); p.dWo = make_fastdiv(wo); p.dHo = make_fastdiv(ho);
     ADA_REQUIRE(ho <= 65535 && batch <= 65535, ADA_EUNSUPPORTED, "ada_bilinear_fwd: ho / batch exceed the grid limits");
     // LDS-tiled path: up-sampling, channels in chunks of 128, source patch of an 8 x 16 output tile within 64 KiB

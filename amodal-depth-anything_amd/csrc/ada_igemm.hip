@@ -55,6 +55,7 @@ struct IgemmDev {
     int map_h, map_w;
     FastDiv dMapW, dMapHW;
     int shuffle_s, shuffle_c;
+    int split_seg;   // > 0: the op-typed output is written as [hi | lo | hi] in three column segments of this width (split precision)
     FastDiv dShC, dShS;
     const float* tail_w;
     float tail_b;
@@ -124,6 +125,39 @@ ADA_DEV opx4 pack4(float4 v) {
     opx4 o;
     o[0] = to_op(v.x); o[1] = to_op(v.y); o[2] = to_op(v.z); o[3] = to_op(v.w);
     return o;
+}
+
+// Operand-typed stores.  With split_seg > 0 the value is written in split precision, hi = round(v) at column n and again at
+// n + 2 seg, lo = round(v - hi) at n + seg: a following contraction over K = 3 seg against weights packed [w_hi | w_hi | w_lo]
+// evaluates x_hi w_hi + x_lo w_hi + x_hi w_lo, i.e. the product to ~fp32 accuracy on the fp16 matrix cores (used for the DPT head of
+// the unbounded-output models).
+ADA_DEV void store_op4(const IgemmDev& p, op_t* dst, float4 v) {
+    const opx4 h = pack4(v);
+    *(opx4*)dst = h;
+    if (p.split_seg > 0) {
+        float4 r;
+        r.x = v.x - (float)h[0]; r.y = v.y - (float)h[1]; r.z = v.z - (float)h[2]; r.w = v.w - (float)h[3];
+        *(opx4*)(dst + p.split_seg) = pack4(r);
+        *(opx4*)(dst + 2 * p.split_seg) = h;
+    }
+}
+ADA_DEV void store_op8(const IgemmDev& p, op_t* dst, float4 v0, float4 v1) {
+    const opx4 lo = pack4(v0), hi4 = pack4(v1);
+    opx8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = hi4[0]; o[5] = hi4[1]; o[6] = hi4[2]; o[7] = hi4[3];
+    *(opx8*)dst = o;
+    if (p.split_seg > 0) {
+        float4 r0, r1;
+        r0.x = v0.x - (float)lo[0]; r0.y = v0.y - (float)lo[1]; r0.z = v0.z - (float)lo[2]; r0.w = v0.w - (float)lo[3];
+        r1.x = v1.x - (float)hi4[0]; r1.y = v1.y - (float)hi4[1]; r1.z = v1.z - (float)hi4[2]; r1.w = v1.w - (float)hi4[3];
+        const opx4 a = pack4(r0), b = pack4(r1);
+        opx8 l;
+        l[0] = a[0]; l[1] = a[1]; l[2] = a[2]; l[3] = a[3];
+        l[4] = b[0]; l[5] = b[1]; l[6] = b[2]; l[7] = b[3];
+        *(opx8*)(dst + p.split_seg) = l;
+        *(opx8*)(dst + 2 * p.split_seg) = o;
+    }
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, bool PHASED = false>
@@ -336,15 +370,28 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             __builtin_amdgcn_s_setprio(0);
         };
         // barrier that ends an L interval: the fragment reads issued in it retire right behind it
+        // optional s_memtime anatomy (ada_debug_set_timestamps): [0] L interval + barrier + fragment-read wait, [1] MFMA issue,
+        // [2] barrier after the MFMAs -- accumulated per wave, written by waves 0 and 4
+        unsigned long long tph[3] = {0, 0, 0}, tprev = 0;
+        auto stamp = [&](int k) {
+            if (p.dbg) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                tph[k] += t - tprev;
+                tprev = t;
+            }
+        };
         auto l_to_m = [&]() {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stamp(0);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto m_to_l = [&]() {
             __builtin_amdgcn_sched_barrier(0);
+            stamp(1);
             __builtin_amdgcn_s_barrier();
+            stamp(2);
             __builtin_amdgcn_sched_barrier(0);
         };
         using I0 = std::integral_constant<int, 0>;
@@ -413,10 +460,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             __builtin_amdgcn_s_barrier();
             if (g1) __builtin_amdgcn_s_barrier();     // group 1 runs one interval behind group 0
             __builtin_amdgcn_sched_barrier(0);
+            if (p.dbg) tprev = __builtin_amdgcn_s_memtime();
         }
         for (int t = 0; t < nk; t += 2) {
             k_tile(I0{}, t);
             if (t + 1 < nk) k_tile(I1{}, t + 1);
+        }
+        if (p.dbg && lane == 0 && (wave & 3) == 0) {
+            unsigned long long* d = p.dbg + ((long)blockIdx.x * 2 + (g1 ? 1 : 0)) * 8;
+            d[0] = tph[0]; d[1] = tph[1]; d[2] = tph[2]; d[3] = (unsigned long long)nk;
         }
         if (!g1) __builtin_amdgcn_s_barrier();        // balances group 1's extra barrier
     } else {
@@ -631,15 +683,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                             v0.x = __builtin_fmaxf(v0.x, 0.f); v0.y = __builtin_fmaxf(v0.y, 0.f); v0.z = __builtin_fmaxf(v0.z, 0.f); v0.w = __builtin_fmaxf(v0.w, 0.f);
                             v1.x = __builtin_fmaxf(v1.x, 0.f); v1.y = __builtin_fmaxf(v1.y, 0.f); v1.z = __builtin_fmaxf(v1.z, 0.f); v1.w = __builtin_fmaxf(v1.w, 0.f);
                         }
-                        const opx4 lo = pack4(v0), hi4 = pack4(v1);
-                        opx8 o;
-                        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-                        o[4] = hi4[0]; o[5] = hi4[1]; o[6] = hi4[2]; o[7] = hi4[3];
                         if (pad) {
-                            *(opx8*)(p.out_op + walk.prow * ld + n) = o;
+                            store_op8(p, p.out_op + walk.prow * ld + n, v0, v1);
                             pad_step(p, walk, RPI);
                         } else {
-                            *(opx8*)(dst + (long)(i * 32 + k * RPI) * ld) = o;
+                            store_op8(p, dst + (long)(i * 32 + k * RPI) * ld, v0, v1);
                         }
                     }
                 }
@@ -713,10 +761,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                             v.z = __builtin_fmaxf(v.z, 0.f); v.w = __builtin_fmaxf(v.w, 0.f);
                         }
                         if (pad) {
-                            *(opx4*)(p.out_op + walk.prow * ldo + n) = pack4(v);
+                            store_op4(p, p.out_op + walk.prow * ldo + n, v);
                             pad_step(p, walk, RPI);
                         } else {
-                            *(opx4*)(p.out_op + (mrow + k * RPI) * ldo + n) = pack4(v);
+                            store_op4(p, p.out_op + (mrow + k * RPI) * ldo + n, v);
                         }
                     }
                 }
@@ -789,15 +837,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                             orow = map_row(p, p.map_op, (uint32_t)m);
                         }
                         op_t* dst = p.out_op + orow * p.ldo_op + ocol;
-                        if (nval2) {
-                            const opx4 lo = pack4(v0), hi4 = pack4(v1);
-                            opx8 o;
-                            o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-                            o[4] = hi4[0]; o[5] = hi4[1]; o[6] = hi4[2]; o[7] = hi4[3];
-                            *(opx8*)dst = o;
-                        } else {
-                            *(opx4*)dst = pack4(v0);
-                        }
+                        if (nval2) store_op8(p, dst, v0, v1);
+                        else store_op4(p, dst, v0);
                     }
                 }
             }
@@ -903,7 +944,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                         } else {
                             orow = map_row(p, p.map_op, (uint32_t)m);
                         }
-                        *(opx4*)(p.out_op + orow * p.ldo_op + ocol) = pack4(v);
+                        store_op4(p, p.out_op + orow * p.ldo_op + ocol, v);
                     }
                 }
             }
@@ -915,7 +956,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             }
         }
     }
-    if (p.dbg && tid == 0) {
+    if (!PHASED && p.dbg && tid == 0) {
         const unsigned long long t_issued = __builtin_amdgcn_s_memtime();   // epilogue instructions issued, stores in flight
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long* d = p.dbg + (long)blockIdx.x * 8;
@@ -1027,7 +1068,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
 
 // ---- tuning / diagnostic hooks (declared in include/ada_hip.h; process-global, not needed for correct operation) ----
 static unsigned long long* g_dbg = nullptr;
-static int g_force_tile = -1, g_short_k_cfg = 3, g_variant = 8;   // variant 8: phased main loop for the 256x256 tile; 0/1/2/4: round-1 loop with its copy-stagger flavours
+static int g_force_tile = -1, g_short_k_cfg = 3, g_variant = 4;   // 0/1/2/4: single-barrier main loop with its copy-stagger flavours (4 = default); 8: phased ping-pong main loop for the 256x256 tile
 static bool g_env_read = false;
 // debug hook (not part of the stable ABI): override the tile configuration (-1 = heuristic)
 extern "C" void ada_debug_set_tile(int cfg) { g_force_tile = cfg; g_env_read = true; }
@@ -1089,6 +1130,11 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
                     "ada_igemm: SHUFFLE needs N == s*s*c");
         ADA_REQUIRE(a->shuffle_c % 4 == 0 && !a->out_f32 && !(f & ADA_EP_GELU), ADA_EUNSUPPORTED, "ada_igemm: SHUFFLE needs c %% 4 == 0, operand output only");
     }
+    if (a->split_seg != 0) {
+        ADA_REQUIRE(a->out_op && a->split_seg > 0 && a->split_seg % 8 == 0 && !swiglu, ADA_EINVAL, "ada_igemm: split_seg needs out_op, a positive multiple of 8, no SwiGLU");
+        const int cols = shuffle ? a->shuffle_c : a->N;
+        ADA_REQUIRE(cols <= a->split_seg && a->ldo_op >= 3L * a->split_seg, ADA_EINVAL, "ada_igemm: split_seg=%d too small for %d columns / ldo_op=%ld", a->split_seg, cols, (long)a->ldo_op);
+    }
     if ((a->out_f32 && a->map_f32 == ADA_MAP_TOKEN) || (a->out_op && a->map_op == ADA_MAP_TOKEN)) {
         ADA_REQUIRE(a->map_h > 0 && a->M % a->map_h == 0, ADA_EINVAL, "ada_igemm: TOKEN map needs map_h = patches per image");
     }
@@ -1112,6 +1158,7 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.dMapW = make_fastdiv(a->map_w > 0 ? a->map_w : 1);
     d.dMapHW = make_fastdiv(token ? a->map_h : (a->map_h > 0 && a->map_w > 0 ? a->map_h * a->map_w : 1));
     d.shuffle_s = a->shuffle_s; d.shuffle_c = a->shuffle_c;
+    d.split_seg = a->split_seg;
     d.dShC = make_fastdiv(a->shuffle_c > 0 ? a->shuffle_c : 1);
     d.dShS = make_fastdiv(a->shuffle_s > 0 ? a->shuffle_s : 1);
     d.tail_w = a->tail_w; d.tail_b = a->tail_b; d.tail_act = a->tail_act;

@@ -35,18 +35,19 @@ def _digest(defines):
     return h.hexdigest()
 
 
-def lib_path(bf16=False):
-    return os.path.join(HERE, "libada_hip_bf16.so" if bf16 else "libada_hip.so")
+def lib_path(bf16=False, tag=None):
+    return os.path.join(HERE, f"libada_hip_{tag}.so" if tag else "libada_hip_bf16.so" if bf16 else "libada_hip.so")
 
 
-def build(bf16=False, force=False, verbose=True):
-    defines = ["-DADA_OPERAND_BF16"] if bf16 else []
-    out = lib_path(bf16)
+def build(bf16=False, force=False, verbose=True, tag=None, extra_defines=()):
+    """tag + extra_defines: experiment builds (libada_hip_<tag>.so with extra -D flags; select with ADA_HIP_LIB)."""
+    defines = (["-DADA_OPERAND_BF16"] if bf16 else []) + list(extra_defines)
+    out = lib_path(bf16, tag)
     stamp = out + ".stamp"
     digest = _digest(defines)
     if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
         return out
-    objdir = os.path.join(HERE, "build", "bf16" if bf16 else "f16")
+    objdir = os.path.join(HERE, "build", tag or ("bf16" if bf16 else "f16"))
     os.makedirs(objdir, exist_ok=True)
     cc = _hipcc()
     common = [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
@@ -77,5 +78,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--force", action="store_true")
+    ap.add_argument("--tag", default=None)
+    ap.add_argument("-D", dest="defs", action="append", default=[])
     a = ap.parse_args()
-    print(build(bf16=a.bf16, force=a.force))
+    print(build(bf16=a.bf16, force=a.force, tag=a.tag, extra_defines=["-D" + d for d in a.defs]))

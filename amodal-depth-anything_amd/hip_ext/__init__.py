@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
 # --- constants mirrored from include/ada_hip.h ------------------------------------------------
-ABI_VERSION = 1
+ABI_VERSION = 2
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 A_PLAIN, A_CONV3 = 0, 1
 MAP_PLAIN, MAP_PAD, MAP_TOKEN, MAP_SHUFFLE = 0, 1, 2, 3
@@ -30,7 +30,7 @@ EXPORTS = (
     "ada_layernorm_fwd", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
     "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd",
     "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
-    "ada_debug_set_timestamps", "ada_debug_set_attention_variant",
+    "ada_debug_set_timestamps", "ada_debug_set_attention_variant", "ada_debug_set_attention_profile",
 )
 
 # indices into the per-image sums of ada_depth_eval_fwd (ADA_EVAL_* in include/ada_hip.h)
@@ -50,7 +50,7 @@ class IgemmArgs(ctypes.Structure):
         ("out_f32", c_void_p), ("ldo_f32", c_int64), ("map_f32", c_int32),
         ("out_op", c_void_p), ("ldo_op", c_int64), ("map_op", c_int32),
         ("map_h", c_int32), ("map_w", c_int32), ("shuffle_s", c_int32), ("shuffle_c", c_int32),
-        ("tail_w", c_void_p), ("tail_b", c_float), ("tail_act", c_int32),
+        ("tail_w", c_void_p), ("tail_b", c_float), ("tail_act", c_int32), ("split_seg", c_int32),
     ]
 
 
@@ -91,7 +91,7 @@ def load(path: Optional[str] = None):
     lib.ada_attention_fwd.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]
     lib.ada_attention_fwd.restype = c_int
     lib.ada_layernorm_fwd.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_float,
-                                      c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p]
+                                      c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p]
     lib.ada_layernorm_fwd.restype = c_int
     lib.ada_patchify.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                  ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p, c_int64, c_int32, c_void_p]
@@ -99,7 +99,7 @@ def load(path: Optional[str] = None):
     lib.ada_write_cls.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
     lib.ada_write_cls.restype = c_int
     lib.ada_bilinear_fwd.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64,
-                                     c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p]
+                                     c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]
     lib.ada_bilinear_fwd.restype = c_int
     lib.ada_selftest.argtypes = [c_void_p, c_int64, c_void_p]
     lib.ada_selftest.restype = c_int
@@ -114,8 +114,9 @@ def load(path: Optional[str] = None):
     for name in ("ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_set_attention_variant"):
         getattr(lib, name).argtypes = [c_int]
         getattr(lib, name).restype = None
-    lib.ada_debug_set_timestamps.argtypes = [c_void_p]
-    lib.ada_debug_set_timestamps.restype = None
+    for name in ("ada_debug_set_timestamps", "ada_debug_set_attention_profile"):
+        getattr(lib, name).argtypes = [c_void_p]
+        getattr(lib, name).restype = None
     lib.ada_debug_last_tile.argtypes = []
     lib.ada_debug_last_tile.restype = c_int
     if lib.ada_abi_version() != ABI_VERSION:
@@ -190,7 +191,7 @@ def set_timer(t: Optional[KernelTimer]):
 # ------------------------------------------------------------------------------------------------
 def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=None, gamma=None, res=None, ldr=0,
           res_row_mod=0, res_row_off=0, flags=0, out_f32=None, ldo_f32=0, map_f32=MAP_PLAIN, out_op=None, ldo_op=0,
-          map_op=MAP_PLAIN, map_h=0, map_w=0, shuffle_s=0, shuffle_c=0, tail_w=None, tail_b=0.0, tail_act=ACT_NONE):
+          map_op=MAP_PLAIN, map_h=0, map_w=0, shuffle_s=0, shuffle_c=0, tail_w=None, tail_b=0.0, tail_act=ACT_NONE, split_seg=0):
     op = operand_dtype()
     a = IgemmArgs()
     a.M, a.N, a.K, a.a_mode = M, N, K, a_mode
@@ -206,6 +207,7 @@ def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=Non
     a.out_op, a.ldo_op, a.map_op = _opt(out_op, "out_op", op), ldo_op, map_op
     a.map_h, a.map_w, a.shuffle_s, a.shuffle_c = map_h, map_w, shuffle_s, shuffle_c
     a.tail_w, a.tail_b, a.tail_act = _opt(tail_w, "tail_w", torch.float32), tail_b, tail_act
+    a.split_seg = split_seg
     if _timer is not None:
         ev = _timer.start()
         _check(load().ada_igemm(ctypes.byref(a), _stream()), "ada_igemm")
@@ -226,12 +228,12 @@ def attention(qkv: torch.Tensor, out: torch.Tensor, batch: int, n_tokens: int, h
 
 
 def layernorm(inp, ld_in, rows_out, dim, weight, bias, eps, *, group_in=0, skip=0, out_op=None, ld_op=0, map_op=MAP_PLAIN,
-              map_h=0, map_w=0, relu=False, out_f32=None, ld_f32=0):
+              map_h=0, map_w=0, relu=False, out_f32=None, ld_f32=0, split_seg=0):
     op = operand_dtype()
     _check(load().ada_layernorm_fwd(_dev(inp, "in", torch.float32), ld_in, rows_out, dim, group_in, skip,
                                     _dev(weight, "weight", torch.float32), _dev(bias, "bias", torch.float32), eps,
                                     _opt(out_op, "out_op", op), ld_op, map_op, map_h, map_w, int(relu),
-                                    _opt(out_f32, "out_f32", torch.float32), ld_f32, _stream()), "ada_layernorm_fwd")
+                                    _opt(out_f32, "out_f32", torch.float32), ld_f32, split_seg, _stream()), "ada_layernorm_fwd")
 
 
 def patchify(x, guide, batch, cg, height, width, mean, inv_std, out, ld, split=False):
@@ -251,11 +253,11 @@ def write_cls(tokens, batch, n_tokens, dim, cls, pos0):
 
 
 def bilinear(inp, ld_in, batch, hi, wi, ho, wo, channels, *, add=None, ld_add=0, out_f32=None, ld_f32=0, out_op=None,
-             ld_op=0, map_op=MAP_PLAIN, relu=False):
+             ld_op=0, map_op=MAP_PLAIN, relu=False, split_seg=0):
     op = operand_dtype()
     _check(load().ada_bilinear_fwd(_dev(inp, "in", torch.float32), ld_in, batch, hi, wi, ho, wo, channels,
                                    _opt(add, "add", torch.float32), ld_add, _opt(out_f32, "out_f32", torch.float32), ld_f32,
-                                   _opt(out_op, "out_op", op), ld_op, map_op, int(relu), _stream()), "ada_bilinear_fwd")
+                                   _opt(out_op, "out_op", op), ld_op, map_op, int(relu), split_seg, _stream()), "ada_bilinear_fwd")
 
 
 def minmax(inp, minmax_out):
@@ -312,7 +314,7 @@ def debug_set_tile(cfg: int = -1):
     load().ada_debug_set_tile(int(cfg))
 
 
-def debug_set_variant(v: int = 8):
+def debug_set_variant(v: int = 4):
     load().ada_debug_set_variant(int(v))
 
 
@@ -324,7 +326,7 @@ def debug_last_tile() -> int:
     return int(load().ada_debug_last_tile())
 
 
-def debug_set_attention_variant(v: int = 0):
+def debug_set_attention_variant(v: int = 5):
     load().ada_debug_set_attention_variant(int(v))
 
 

@@ -54,11 +54,16 @@ class PackedWeights:
     """Operand-typed copies of the parameters, laid out for the kernels.  ``sd``: name -> fp32 CUDA tensor
     with the *raw* model's key names (``pretrained.*``, ``depth_head.*``)."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], encoder: str, guided: bool, amodal_head: bool):
+    def __init__(self, sd: Dict[str, torch.Tensor], encoder: str, guided: bool, amodal_head: bool, split_head: bool = False):
         op = operand_dtype()
         cfg = VIT[encoder]
         D = cfg["dim"]
         self.encoder, self.guided, self.amodal_head = encoder, guided, amodal_head
+        # split_head: every contraction of the DPT head runs in split precision -- activations are stored as [hi | lo | hi]
+        # column segments by the producing kernel (split_seg) and weights are packed [w_hi | w_hi | w_lo], so one fp16 GEMM over
+        # 3x the K evaluates x_hi w_hi + x_lo w_hi + x_hi w_lo (~fp32 operand accuracy).  Used where the head's operand rounding
+        # is what limits parity: the unbounded-output models (raw ReLU / 'ssi' heads) and ViT-S (DESIGN.md section 3).
+        self.split_head = split_head
         self.dim, self.depth, self.heads, self.ffn = D, cfg["depth"], cfg["heads"], cfg["ffn"]
 
         def f32(name):
@@ -139,6 +144,26 @@ class PackedWeights:
             self.blocks.append(blk)
         self.norm_w, self.norm_b = f32(p + "norm.weight"), f32(p + "norm.bias")
 
+        if split_head:   # from here on only head weights are packed
+            def triple(w2d):   # [..., K] fp32, K already padded to a multiple of 64
+                hi = w2d.to(op)
+                lo = (w2d - hi.float()).to(op)
+                return torch.cat([hi, hi, lo], dim=-1)
+
+            def lin(w):  # noqa: F811
+                w = w.reshape(w.shape[0], -1)
+                k = w.shape[1]
+                if k % 64:
+                    w = F.pad(w, (0, _r64(k) - k))
+                return triple(w).contiguous()
+
+            def conv3(w):  # noqa: F811  [Co, Ci, 3, 3] -> [Co, 9 * 3 * Cip]: per tap [hi | hi | lo]
+                co, ci = w.shape[:2]
+                w = w.permute(0, 2, 3, 1)
+                if ci % 64:
+                    w = F.pad(w, (0, _r64(ci) - ci))
+                return triple(w).reshape(co, -1).contiguous()
+
         h = "depth_head."
         self.oc = [sd[f"{h}projects.{i}.weight"].shape[0] for i in range(4)]
         self.features = sd[h + "scratch.layer1_rn.weight"].shape[0]
@@ -202,6 +227,7 @@ class Workspace:
         T, P = B * N, B * Np
         Fch = pw_.features
         Fp = _r64(Fch)
+        m = 3 if pw_.split_head else 1     # split-precision head: op-typed head tensors hold [hi | lo | hi] segments
 
         def z(*shape, dtype=op):
             return torch.zeros(*shape, dtype=dtype, device=device)
@@ -213,33 +239,34 @@ class Workspace:
         self.o = z(T, D)
         hidden = pw_.blocks[0]["hidden"]
         self.hd = z(T, hidden)
-        self.taps = [z(P, D) for _ in range(4)]
+        self.taps = [z(P, m * D) for _ in range(4)]
         # head grids
         self.grid = [(4 * ph, 4 * pw), (2 * ph, 2 * pw), (ph, pw), ((ph - 1) // 2 + 1, (pw - 1) // 2 + 1)]
         oc = pw_.oc
         ocp = [_r64(c) for c in oc]
-        self.t0 = z(P, ocp[0])
-        self.t1 = z(P, ocp[1])
-        self.pre3 = z(B, ph + 2, pw + 2, ocp[3])
-        self.L = [z(B, g[0] + 2, g[1] + 2, ocp[i]) for i, g in enumerate(self.grid)]
+        self.ocp, self.Fp = ocp, Fp
+        self.t0 = z(P, m * ocp[0])
+        self.t1 = z(P, m * ocp[1])
+        self.pre3 = z(B, ph + 2, pw + 2, m * ocp[3])
+        self.L = [z(B, g[0] + 2, g[1] + 2, m * ocp[i]) for i, g in enumerate(self.grid)]
         if pw_.amodal_head:
             self.ipf = [z(B * g[0] * g[1], oc[i], dtype=torch.float32) for i, g in enumerate(self.grid)]
-            self.L2 = [z(B, g[0] + 2, g[1] + 2, ocp[i]) for i, g in enumerate(self.grid)]
+            self.L2 = [z(B, g[0] + 2, g[1] + 2, m * ocp[i]) for i, g in enumerate(self.grid)]
         self.rnx = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
-        self.rnr = [z(B, g[0] + 2, g[1] + 2, Fp) for g in self.grid]
-        self.tmpa = [z(B, g[0] + 2, g[1] + 2, Fp) for g in self.grid]
+        self.rnr = [z(B, g[0] + 2, g[1] + 2, m * Fp) for g in self.grid]
+        self.tmpa = [z(B, g[0] + 2, g[1] + 2, m * Fp) for g in self.grid]
         self.r = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
         self.s = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
-        self.sr = [z(B, g[0] + 2, g[1] + 2, Fp) for g in self.grid]
-        self.u = [z(B * g[0] * g[1], Fp) for g in self.grid]
+        self.sr = [z(B, g[0] + 2, g[1] + 2, m * Fp) for g in self.grid]
+        self.u = [z(B * g[0] * g[1], m * Fp) for g in self.grid]
         self.zf = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
         g0 = self.grid[0]
         self.g296 = (2 * g0[0], 2 * g0[1])
-        self.p1 = z(B, self.g296[0] + 2, self.g296[1] + 2, Fp)
+        self.p1 = z(B, self.g296[0] + 2, self.g296[1] + 2, m * Fp)
         half = Fch // 2
         self.half, self.halfp = half, _r64(half)
         self.oc1 = z(B * self.g296[0] * self.g296[1], half, dtype=torch.float32)
-        self.fin = z(B, H + 2, W + 2, self.halfp)
+        self.fin = z(B, H + 2, W + 2, m * self.halfp)
 
 
 class DepthEngine:
@@ -319,7 +346,9 @@ class DepthEngine:
                 k_igemm(M=T, N=D, K=hid, A=ws.hd, lda=hid, W=blk["w3_w"], bias=blk["w3_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
                         flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D)
             if i in taps:  # shared final LayerNorm on the tap, cls row dropped (dinov2.py:337-340)
-                k_layernorm(ws.x, D, P, D, w.norm_w, w.norm_b, LN_EPS, group_in=N, skip=1, out_op=ws.taps[taps.index(i)], ld_op=D)
+                tap = ws.taps[taps.index(i)]
+                k_layernorm(ws.x, D, P, D, w.norm_w, w.norm_b, LN_EPS, group_in=N, skip=1, out_op=tap, ld_op=tap.shape[1],
+                            split_seg=D if w.split_head else 0)
 
         return self._head(ws, B)
 
@@ -333,40 +362,47 @@ class DepthEngine:
         grid = ws.grid
         rows = [B * g[0] * g[1] for g in grid]
 
+        sp = w.split_head
+        ocp, Fp = ws.ocp, ws.Fp
+
+        def S(seg):   # split_seg argument of a producer whose consumer reads [hi | lo | hi] segments of width seg
+            return seg if sp else 0
+
         # ---- reassemble: 1x1 project + resize (dpt.py:171-173) -> zero-bordered NHWC operand tensors -----
-        k_igemm(M=P, N=oc[0], K=D, A=ws.taps[0], lda=D, W=w.proj_w[0], bias=w.proj_b[0], flags=EP_BIAS, out_op=ws.t0, ldo_op=ws.t0.shape[1])
-        k_igemm(M=P, N=16 * oc[0], K=ws.t0.shape[1], A=ws.t0, lda=ws.t0.shape[1], W=w.rs0_w, bias=w.rs0_b, flags=EP_BIAS,
-                out_op=ws.L[0], ldo_op=ws.L[0].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=4, shuffle_c=oc[0])
-        k_igemm(M=P, N=oc[1], K=D, A=ws.taps[1], lda=D, W=w.proj_w[1], bias=w.proj_b[1], flags=EP_BIAS, out_op=ws.t1, ldo_op=ws.t1.shape[1])
-        k_igemm(M=P, N=4 * oc[1], K=ws.t1.shape[1], A=ws.t1, lda=ws.t1.shape[1], W=w.rs1_w, bias=w.rs1_b, flags=EP_BIAS,
-                out_op=ws.L[1], ldo_op=ws.L[1].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=2, shuffle_c=oc[1])
-        k_igemm(M=P, N=oc[2], K=D, A=ws.taps[2], lda=D, W=w.proj_w[2], bias=w.proj_b[2], flags=EP_BIAS,
-                out_op=ws.L[2], ldo_op=ws.L[2].shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw)
-        k_igemm(M=P, N=oc[3], K=D, A=ws.taps[3], lda=D, W=w.proj_w[3], bias=w.proj_b[3], flags=EP_BIAS,
-                out_op=ws.pre3, ldo_op=ws.pre3.shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw)
-        self._conv3(ws.pre3, w.rs3_w, rows[3], oc[3], grid[3], stride=2, bias=w.rs3_b, flags=EP_BIAS,
-                    out_op=ws.L[3], ldo_op=ws.L[3].shape[3], map_op=MAP_PAD, map_h=grid[3][0], map_w=grid[3][1])
+        KD = ws.taps[0].shape[1]
+        k_igemm(M=P, N=oc[0], K=KD, k_alg=D, A=ws.taps[0], lda=KD, W=w.proj_w[0], bias=w.proj_b[0], flags=EP_BIAS, out_op=ws.t0, ldo_op=ws.t0.shape[1], split_seg=S(ocp[0]))
+        k_igemm(M=P, N=16 * oc[0], K=ws.t0.shape[1], k_alg=oc[0], A=ws.t0, lda=ws.t0.shape[1], W=w.rs0_w, bias=w.rs0_b, flags=EP_BIAS,
+                out_op=ws.L[0], ldo_op=ws.L[0].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=4, shuffle_c=oc[0], split_seg=S(ocp[0]))
+        k_igemm(M=P, N=oc[1], K=KD, k_alg=D, A=ws.taps[1], lda=KD, W=w.proj_w[1], bias=w.proj_b[1], flags=EP_BIAS, out_op=ws.t1, ldo_op=ws.t1.shape[1], split_seg=S(ocp[1]))
+        k_igemm(M=P, N=4 * oc[1], K=ws.t1.shape[1], k_alg=oc[1], A=ws.t1, lda=ws.t1.shape[1], W=w.rs1_w, bias=w.rs1_b, flags=EP_BIAS,
+                out_op=ws.L[1], ldo_op=ws.L[1].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=2, shuffle_c=oc[1], split_seg=S(ocp[1]))
+        k_igemm(M=P, N=oc[2], K=KD, k_alg=D, A=ws.taps[2], lda=KD, W=w.proj_w[2], bias=w.proj_b[2], flags=EP_BIAS,
+                out_op=ws.L[2], ldo_op=ws.L[2].shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S(ocp[2]))
+        k_igemm(M=P, N=oc[3], K=KD, k_alg=D, A=ws.taps[3], lda=KD, W=w.proj_w[3], bias=w.proj_b[3], flags=EP_BIAS,
+                out_op=ws.pre3, ldo_op=ws.pre3.shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S(ocp[3]))
+        self._conv3(ws.pre3, w.rs3_w, rows[3], oc[3], grid[3], stride=2, cin=oc[3], bias=w.rs3_b, flags=EP_BIAS,
+                    out_op=ws.L[3], ldo_op=ws.L[3].shape[3], map_op=MAP_PAD, map_h=grid[3][0], map_w=grid[3][1], split_seg=S(ocp[3]))
 
         # ---- amodal only: input_projection = conv3x3 -> channels-first LN -> ReLU (dpt.py:153-159,178-179) ----
         layers = ws.L
         if w.amodal_head:
             for i in range(4):
-                self._conv3(ws.L[i], w.ip_w[i], rows[i], oc[i], grid[i], bias=w.ip_b[i], flags=EP_BIAS, out_f32=ws.ipf[i], ldo_f32=oc[i])
+                self._conv3(ws.L[i], w.ip_w[i], rows[i], oc[i], grid[i], cin=oc[i], bias=w.ip_b[i], flags=EP_BIAS, out_f32=ws.ipf[i], ldo_f32=oc[i])
                 k_layernorm(ws.ipf[i], oc[i], rows[i], oc[i], w.ip_ln_w[i], w.ip_ln_b[i], LN_EPS, out_op=ws.L2[i],
-                            ld_op=ws.L2[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], relu=True)
+                            ld_op=ws.L2[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], relu=True, split_seg=S(ocp[i]))
             layers = ws.L2
 
         # ---- layerN_rn (blocks.py:20-24): fp32 copy for the residual adds + ReLU'd operand copy for conv1 ----
         for i in range(4):
-            self._conv3(layers[i], w.rn_w[i], rows[i], Fch, grid[i], flags=EP_RELU_OP, out_f32=ws.rnx[i], ldo_f32=Fch,
-                        out_op=ws.rnr[i], ldo_op=ws.rnr[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1])
+            self._conv3(layers[i], w.rn_w[i], rows[i], Fch, grid[i], cin=oc[i], flags=EP_RELU_OP, out_f32=ws.rnx[i], ldo_f32=Fch,
+                        out_op=ws.rnr[i], ldo_op=ws.rnr[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], split_seg=S(Fp))
 
         def rcu(i, fw, unit, src_relu_pad, src_f32, **out):
             """ResidualConvUnit (blocks.py:57-80) at grid i: conv2(relu(conv1(relu(x)))) + x."""
             g = grid[i]
-            self._conv3(src_relu_pad, fw[f"u{unit}c1_w"], rows[i], Fch, g, bias=fw[f"u{unit}c1_b"], flags=EP_BIAS | EP_RELU_OP,
-                        out_op=ws.tmpa[i], ldo_op=ws.tmpa[i].shape[3], map_op=MAP_PAD, map_h=g[0], map_w=g[1])
-            self._conv3(ws.tmpa[i], fw[f"u{unit}c2_w"], rows[i], Fch, g, bias=fw[f"u{unit}c2_b"], res=src_f32, ldr=Fch,
+            self._conv3(src_relu_pad, fw[f"u{unit}c1_w"], rows[i], Fch, g, cin=Fch, bias=fw[f"u{unit}c1_b"], flags=EP_BIAS | EP_RELU_OP,
+                        out_op=ws.tmpa[i], ldo_op=ws.tmpa[i].shape[3], map_op=MAP_PAD, map_h=g[0], map_w=g[1], split_seg=S(Fp))
+            self._conv3(ws.tmpa[i], fw[f"u{unit}c2_w"], rows[i], Fch, g, cin=Fch, bias=fw[f"u{unit}c2_b"], res=src_f32, ldr=Fch,
                         flags=EP_BIAS | EP_RESIDUAL, **out)
 
         # ---- refinenet4..1 (blocks.py:123-148).  out_conv is applied BEFORE the bilinear resize: both are linear and
@@ -374,22 +410,22 @@ class DepthEngine:
         s_f32, s_pad = ws.rnx[3], ws.rnr[3]
         for i in (3, 2, 1, 0):
             fw = w.fuse[i]
-            rcu(i, fw, 2, s_pad, s_f32, out_op=ws.u[i], ldo_op=ws.u[i].shape[1])
-            k_igemm(M=rows[i], N=Fch, K=ws.u[i].shape[1], A=ws.u[i], lda=ws.u[i].shape[1], W=fw["out_w"], bias=fw["out_b"], flags=EP_BIAS,
+            rcu(i, fw, 2, s_pad, s_f32, out_op=ws.u[i], ldo_op=ws.u[i].shape[1], split_seg=S(Fp))
+            k_igemm(M=rows[i], N=Fch, K=ws.u[i].shape[1], k_alg=Fch, A=ws.u[i], lda=ws.u[i].shape[1], W=fw["out_w"], bias=fw["out_b"], flags=EP_BIAS,
                     out_f32=ws.zf[i], ldo_f32=Fch)
             if i > 0:
                 j = i - 1
                 rcu(j, w.fuse[j], 1, ws.rnr[j], ws.rnx[j], out_f32=ws.r[j], ldo_f32=Fch)
                 k_bilinear(ws.zf[i], Fch, B, grid[i][0], grid[i][1], grid[j][0], grid[j][1], Fch, add=ws.r[j], ld_add=Fch,
-                           out_f32=ws.s[j], ld_f32=Fch, out_op=ws.sr[j], ld_op=ws.sr[j].shape[3], map_op=MAP_PAD, relu=True)
+                           out_f32=ws.s[j], ld_f32=Fch, out_op=ws.sr[j], ld_op=ws.sr[j].shape[3], map_op=MAP_PAD, relu=True, split_seg=S(Fp))
                 s_f32, s_pad = ws.s[j], ws.sr[j]
         g2 = ws.g296
-        k_bilinear(ws.zf[0], Fch, B, grid[0][0], grid[0][1], g2[0], g2[1], Fch, out_op=ws.p1, ld_op=ws.p1.shape[3], map_op=MAP_PAD)
+        k_bilinear(ws.zf[0], Fch, B, grid[0][0], grid[0][1], g2[0], g2[1], Fch, out_op=ws.p1, ld_op=ws.p1.shape[3], map_op=MAP_PAD, split_seg=S(Fp))
 
         # ---- output_conv1 -> resize to (14 ph, 14 pw) -> output_conv2 (3x3, ReLU, 1x1, activation) (dpt.py:193-195) ----
-        self._conv3(ws.p1, w.oc1_w, B * g2[0] * g2[1], ws.half, g2, bias=w.oc1_b, flags=EP_BIAS, out_f32=ws.oc1, ldo_f32=ws.half)
-        k_bilinear(ws.oc1, ws.half, B, g2[0], g2[1], ws.H, ws.W, ws.half, out_op=ws.fin, ld_op=ws.fin.shape[3], map_op=MAP_PAD)
+        self._conv3(ws.p1, w.oc1_w, B * g2[0] * g2[1], ws.half, g2, cin=Fch, bias=w.oc1_b, flags=EP_BIAS, out_f32=ws.oc1, ldo_f32=ws.half)
+        k_bilinear(ws.oc1, ws.half, B, g2[0], g2[1], ws.H, ws.W, ws.half, out_op=ws.fin, ld_op=ws.fin.shape[3], map_op=MAP_PAD, split_seg=S(ws.halfp))
         out = torch.empty(B, 1, ws.H, ws.W, dtype=torch.float32, device=ws.fin.device)
-        self._conv3(ws.fin, w.oc2_w, B * ws.H * ws.W, w.oc2_w.shape[0], (ws.H, ws.W), bias=w.oc2_b, flags=EP_BIAS | EP_TAIL,
+        self._conv3(ws.fin, w.oc2_w, B * ws.H * ws.W, w.oc2_w.shape[0], (ws.H, ws.W), cin=ws.half, bias=w.oc2_b, flags=EP_BIAS | EP_TAIL,
                     out_f32=out, ldo_f32=1, tail_w=w.tail_w, tail_b=w.tail_b, tail_act=self.final_act)
         return out

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADA_ABI_VERSION 1
+#define ADA_ABI_VERSION 2
 
 /* status codes */
 #define ADA_OK 0
@@ -124,6 +124,8 @@ typedef struct ada_igemm_args {
     const float* tail_w;    /* TAIL: [N] fp32 */
     float tail_b;
     int32_t tail_act;
+    int32_t split_seg;      /* > 0: split-precision op output -- out_op receives [hi | lo | hi] in three column segments of
+                               split_seg elements (hi = round(v), lo = round(v - hi)); 0 = plain */
 } ada_igemm_args;
 
 int ada_igemm(const ada_igemm_args* args, void* stream);
@@ -149,14 +151,15 @@ int ada_attention_fwd(const void* qkv, void* out, int32_t batch, int32_t n_token
  * Row selection: group_in > 0 treats the input as groups of `group_in` rows and skips the first
  * `skip` rows of each group (drops the cls token: dinov2.py:339-340); output rows are compacted.
  * Output (either may be NULL): op-typed with row map (PLAIN or PAD) and optional ReLU
- * (DA2/dpt.py:158), and/or fp32 plain.
+ * (DA2/dpt.py:158), and/or fp32 plain.  split_seg > 0 writes the op-typed output in split precision
+ * ([hi | lo | hi] column segments, see ada_igemm_args.split_seg).
  * ---------------------------------------------------------------------------------------- */
 int ada_layernorm_fwd(const float* in, int64_t ld_in, int32_t rows_out, int32_t dim,
                       int32_t group_in, int32_t skip,
                       const float* weight, const float* bias, float eps,
                       void* out_op, int64_t ld_op, int32_t map_op, int32_t map_h, int32_t map_w,
                       int32_t relu,
-                      float* out_f32, int64_t ld_f32, void* stream);
+                      float* out_f32, int64_t ld_f32, int32_t split_seg, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Patchify: the im2col half of the 14x14/stride-14 patch-embed convolutions
@@ -184,12 +187,12 @@ int ada_write_cls(float* tokens, int32_t batch, int32_t n_tokens, int32_t dim, c
  * Replaces F.interpolate at DA2/util/blocks.py:144 and DA2/dpt.py:194, and the skip_add of
  * DA2/util/blocks.py:133.  Outputs (either may be NULL): fp32 plain [B*Ho*Wo, ld_f32]; op-typed
  * with row map PLAIN or PAD and optional ReLU (the activation opening the next ResidualConvUnit,
- * DA2/util/blocks.py:67).
+ * DA2/util/blocks.py:67).  split_seg > 0: split-precision op output as in ada_igemm_args.split_seg.
  * ---------------------------------------------------------------------------------------- */
 int ada_bilinear_fwd(const float* in, int64_t ld_in, int32_t batch, int32_t hi, int32_t wi,
                      int32_t ho, int32_t wo, int32_t channels, const float* add, int64_t ld_add,
                      float* out_f32, int64_t ld_f32, void* out_op, int64_t ld_op, int32_t map_op,
-                     int32_t relu, void* stream);
+                     int32_t relu, int32_t split_seg, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Depth evaluation sums.  Replaces the host-side numpy/torch evaluation of the reference:
@@ -249,15 +252,18 @@ int ada_selftest(void* scratch, int64_t scratch_bytes, void* stream);
  * the same switches once, at the first ada_igemm call.
  *   ada_debug_set_tile(cfg)      force the ada_igemm tile: 0 256x32, 1 128x64, 2 256x128, 3 256x256,
  *                                4 128x128, 5 128x256x32, 7 512x128; -1 = heuristic (default)
- *   ada_debug_set_variant(v)     main loop of the 256x256 tile: 8 = phased ping-pong loop (default);
- *                                0/1/2/4 = single-barrier loop with its copy-stagger flavours
+ *   ada_debug_set_variant(v)     main loop of the 256x256 tile: 0/1/2/4 = single-barrier loop with its copy-stagger
+ *                                flavours (4 = default); 8 = phased ping-pong loop (same speed under the power cap)
  *   ada_debug_set_group(g)       force the column-group width of the tile order (0 = traffic model)
  *   ada_debug_last_tile()        tile code of the calling thread's most recent ada_igemm launch
  *                                (+100 when the phased main loop ran), -1 before the first launch
  *   ada_debug_set_timestamps(p)  device buffer of 8 x u64 per workgroup receiving s_memtime stamps
  *                                of the single-barrier loop, or NULL (default)
- *   ada_debug_set_attention_variant(v)  0 = 8-wave ping-pong kernel with static priority (default),
- *                                1 = the same without s_setprio, 3 = the 4-wave round-1 kernel
+ *   ada_debug_set_attention_variant(v)  5 = 4-wave kernel with the softmax interleaved between its MFMAs (default),
+ *                                0 = 8-wave ping-pong kernel with static priority,
+ *                                1 = the same without s_setprio, 2 = the same with per-wave s_memtime
+ *                                interval stamps written to the ada_debug_set_attention_profile buffer
+ *                                (8 x u64 per wave), 3 = the 4-wave round-1 kernel
  * ---------------------------------------------------------------------------------------- */
 void ada_debug_set_tile(int cfg);
 void ada_debug_set_variant(int v);
@@ -265,6 +271,7 @@ void ada_debug_set_group(int g);
 int ada_debug_last_tile(void);
 void ada_debug_set_timestamps(void* dev_buf);
 void ada_debug_set_attention_variant(int v);
+void ada_debug_set_attention_profile(void* dev_buf);
 
 #ifdef __cplusplus
 }

@@ -1,13 +1,18 @@
 """Multi-GPU batched inference: one process per GPU, images sharded over ranks, ONE all-gather of the per-image
-depth maps (RCCL over xGMI when the process group is 'nccl'; the same code runs on 'gloo' for CPU tests).
+depth maps (RCCL over xGMI when the process group is 'nccl'; the same code runs on 'gloo' for the CPU tests).
 
 The forward pass has no cross-image operation (no BatchNorm; LayerNorm and attention are per image -- SURVEY.md §8e),
 so weights are replicated and the only exchange is the output gather: [B_local, 1, H, W] fp32 per rank
 (1.07 MB per 518x518 image).  The reference has no counterpart: its inference is single-process (infer.py:59-69).
+
+``DepthGather`` owns the pre-sized buffers of that exchange and is the ONE collective path of this package:
+``sharded_forward`` (global batch in, global batch out), ``bench.py --gpus N`` (per-rank synthetic shards, asynchronous
+gather riding under the next forward) and ``src/scripts/amodal_dav2_inference.py`` (dataset sharded over ranks) all go
+through it.  No pickled metadata, no per-call allocation: shard sizes follow from (batch, world) alone.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Sequence, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -20,34 +25,97 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _world(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+class DepthGather:
+    """Pre-sized all-gather of per-item outputs over a process group.
+
+    ``batch`` is the GLOBAL number of items; rank r owns ``shard_range(batch, r, world)``.  When the shards are even the
+    collective writes straight into the ``[batch, *item_shape]`` result; otherwise every rank sends a buffer padded to the
+    largest shard and the valid rows are compacted afterwards."""
+
+    def __init__(self, batch: int, item_shape: Sequence[int], dtype: torch.dtype, device, group=None):
+        self.group = group
+        self.rank, self.world = _world(group)
+        self.batch, self.item_shape = int(batch), tuple(int(s) for s in item_shape)
+        self.spans: List[Tuple[int, int]] = [shard_range(self.batch, r, self.world) for r in range(self.world)]
+        self.lo, self.hi = self.spans[self.rank]
+        self.cap = max(h - l for l, h in self.spans) if self.spans else 0
+        self.even = all(h - l == self.cap for l, h in self.spans)
+        self.recv = torch.empty((self.world * self.cap,) + self.item_shape, dtype=dtype, device=device)
+        self.send = None if self.even else torch.zeros((self.cap,) + self.item_shape, dtype=dtype, device=device)
+        self._pending = None
+
+    def start(self, local: Optional[torch.Tensor]):
+        """Issues the collective for this rank's ``[hi - lo, *item_shape]`` output (``None`` for an empty shard) and returns
+        at once; ``finish()`` completes it.  At most one gather is in flight per object."""
+        self.finish_pending()
+        n = self.hi - self.lo
+        if n > 0:
+            assert local is not None and tuple(local.shape) == (n,) + self.item_shape, \
+                f"rank {self.rank}: expected {(n,) + self.item_shape}, got {None if local is None else tuple(local.shape)}"
+        if self.world == 1:
+            self.recv[:n].copy_(local)
+            return
+        if self.even:
+            src = local.contiguous()
+        else:
+            src = self.send
+            if n > 0:
+                src[:n].copy_(local)
+        self._pending = dist.all_gather_into_tensor(self.recv, src, group=self.group, async_op=True)
+
+    def finish_pending(self):
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
+
+    def finish(self) -> torch.Tensor:
+        """Waits for the gather in flight and returns the global ``[batch, *item_shape]`` result (a view of the receive
+        buffer for even shards; it is overwritten by the next ``start``)."""
+        self.finish_pending()
+        if self.even:
+            return self.recv[: self.batch]
+        return torch.cat([self.recv[r * self.cap: r * self.cap + (h - l)] for r, (l, h) in enumerate(self.spans)], dim=0)
+
+    def gather(self, local: Optional[torch.Tensor]) -> torch.Tensor:
+        self.start(local)
+        return self.finish()
+
+
+_gathers = {}
+
+
 def sharded_forward(forward: Callable[..., torch.Tensor], inputs: Sequence[Optional[torch.Tensor]], group=None,
-                    gather: bool = True) -> torch.Tensor:
+                    gather: bool = True, item_shape: Optional[Sequence[int]] = None,
+                    dtype: torch.dtype = torch.float32) -> Optional[torch.Tensor]:
     """Runs ``forward(*inputs_local)`` on this rank's slice of the batch dimension and (optionally) all-gathers the
     outputs so that every rank returns the full ``[B, ...]`` result in the original order.
 
-    ``inputs`` are the *global* batch tensors (``None`` entries are passed through).  Uneven batches are handled by
-    padding the gathered buffers to the largest shard; ranks with an empty shard contribute nothing.
-    """
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    batch = next(t.shape[0] for t in inputs if t is not None)
+    ``inputs`` are the *global* batch tensors (``None`` entries are passed through).  ``item_shape`` / ``dtype`` describe
+    one output item; they default to the depth-map convention of this package, ``[1, H, W]`` fp32 with H, W the trailing
+    dims of the first input -- every rank can derive them locally, including a rank whose shard is empty."""
+    rank, world = _world(group)
+    first = next(t for t in inputs if t is not None)
+    batch = first.shape[0]
     lo, hi = shard_range(batch, rank, world)
     local = None
     if hi > lo:
         local = forward(*[None if t is None else t[lo:hi] for t in inputs])
     if world == 1 or not gather:
         return local
-    # every rank must know the per-item shape/dtype/device even when its own shard is empty
-    meta = [None] * world
-    dist.all_gather_object(meta, None if local is None else (tuple(local.shape[1:]), str(local.dtype), str(local.device)), group=group)
-    item_shape, dtype_s, dev_s = next(m for m in meta if m is not None)
-    dtype = getattr(torch, dtype_s.split(".")[-1])
-    device = local.device if local is not None else torch.device(dev_s if not dev_s.startswith("cuda") else f"cuda:{torch.cuda.current_device()}")
-    sizes = [shard_range(batch, r, world) for r in range(world)]
-    cap = max(h - l for l, h in sizes)
-    send = torch.zeros((cap,) + item_shape, dtype=dtype, device=device)
+    if item_shape is None:
+        item_shape = tuple(local.shape[1:]) if local is not None else (1,) + tuple(first.shape[-2:])
     if local is not None:
-        send[: hi - lo] = local
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)
-    return torch.cat([recv[r][: h - l] for r, (l, h) in enumerate(sizes)], dim=0)
+        dtype = local.dtype
+    key = (batch, tuple(item_shape), dtype, str(first.device), id(group))
+    g = _gathers.get(key)
+    if g is None:
+        if len(_gathers) > 8:
+            _gathers.clear()
+        g = _gathers[key] = DepthGather(batch, item_shape, dtype, first.device, group)
+    return g.gather(local).clone()

@@ -10,6 +10,10 @@ when a ground-truth depth directory is given, evaluates on the device: per-sampl
 
     python -m src.scripts.amodal_dav2_inference --trained_checkpoint DIR --occ_image_dir A --whole_mask_dir B \
         --observation_depth_dir C --output_dir OUT [--gt_depth_dir D] [--split_file val.txt] [--batch_size 32]
+
+Multi-GPU: launch one process per GPU (``python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 -m
+src.scripts.amodal_dav2_inference ...``).  The sample list is sharded contiguously over the ranks (hip_ext.parallel.shard_range),
+each rank writes its own PNGs, and the per-sample metric sums are combined with one all-reduce at the end.
 """
 import argparse
 import json
@@ -59,20 +63,36 @@ def load_sample(sid: str, occ_image_dir: str, whole_mask_dir: str, observation_d
 
 
 def run(model: Callable, ids: List[str], occ_image_dir: str, whole_mask_dir: str, observation_depth_dir: str, output_dir: str,
-        gt_depth_dir: Optional[str] = None, batch_size: int = 32, device: str = "cuda", evaluate: Optional[Callable] = None) -> Dict[str, float]:
+        gt_depth_dir: Optional[str] = None, batch_size: int = 32, device: str = "cuda", evaluate: Optional[Callable] = None,
+        group=None) -> Dict[str, float]:
     """Runs the model over ``ids`` in batches, writes ``{output_dir}/amodal_depth/{id}_depth.png`` (uint16, depth * 65535, :124-125)
-    and returns the averaged metrics when ground truth is available.  ``evaluate(pred, gt, mask) -> dict`` defaults to the device path."""
+    and returns the per-sample metrics averaged over the samples when ground truth is available.  ``evaluate(pred, gt, mask) -> dict``
+    (applied to one sample at a time) defaults to the device path."""
     out_depth = os.path.join(output_dir, "amodal_depth")
     os.makedirs(out_depth, exist_ok=True)
+    # Metrics follow the reference's evaluation semantics -- one sample at a time (its loader runs batch size 1), then the mean over
+    # the samples -- so the result does not depend on how the samples are batched or sharded (silog_rmse and log10 are not linear
+    # in the batch).  ``evaluate(pred, gt, mask) -> dict`` is applied per sample; the default computes the per-image sums of the
+    # whole batch in one device pass and derives each sample's metrics from its own row.
+    per_sample = None
     if gt_depth_dir and evaluate is None:
         from src.util import alignment, metric
 
-        def evaluate(pred, gt, mask):
+        def per_sample(pred, gt, mask):
             ss = alignment.scale_shift_least_square(gt, pred, mask)            # per-sample (scale, shift), fp64 [B,2]
             import hip_ext as H
             sums = H.depth_eval(pred.contiguous().float(), gt.contiguous().float(), mask.contiguous(), scale_shift=ss.float().contiguous(),
                                 clip=(1e-3, 1.0))                              # aligned prediction clamped to the PNG depth range
-            return {k: float(v) for k, v in metric._from_sums(sums).items()}
+            return [{k: float(v) for k, v in metric._from_sums(sums[b:b + 1]).items()} for b in range(pred.shape[0])]
+    elif gt_depth_dir:
+        def per_sample(pred, gt, mask):
+            return [evaluate(pred[b:b + 1], gt[b:b + 1], mask[b:b + 1]) for b in range(pred.shape[0])]
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if world > 1:   # this rank's contiguous share of the sample list
+        from hip_ext.parallel import shard_range
+        lo, hi = shard_range(len(ids), dist.get_rank(group), world)
+        ids = ids[lo:hi]
     totals: Dict[str, float] = {}
     count = 0
     for i in range(0, len(ids), batch_size):
@@ -90,10 +110,20 @@ def run(model: Callable, ids: List[str], occ_image_dir: str, whole_mask_dir: str
         if gt_depth_dir:
             gt = torch.stack([s["gt_depth"] for s in samples]).to(device).reshape(len(chunk), *RESIZE_HW)
             valid = mask.reshape(len(chunk), *RESIZE_HW) & (gt > 0)
-            res = evaluate(depth.float(), gt, valid)
-            for k, v in res.items():
-                totals[k] = totals.get(k, 0.0) + v * len(chunk)
+            for res in per_sample(depth.float(), gt, valid):
+                for k, v in res.items():
+                    totals[k] = totals.get(k, 0.0) + v
             count += len(chunk)
+    if world > 1 and gt_depth_dir:
+        # metric names are fixed by the evaluator, so every rank (also one with an empty share) builds the same vector
+        keys = sorted(totals) if totals else None
+        names = [None] * world
+        dist.all_gather_object(names, keys, group=group)          # control plane only: a list of metric names
+        keys = next((k for k in names if k), [])
+        vec = torch.tensor([totals.get(k, 0.0) for k in keys] + [float(count)], dtype=torch.float64, device=device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(vec, group=group)
+        count = int(vec[-1].item())
+        totals = {k: float(v) for k, v in zip(keys, vec[:-1].tolist())}
     return {k: v / count for k, v in totals.items()} if count else {}
 
 
@@ -112,6 +142,17 @@ def main(argv=None):
     ap.add_argument("--batch_size", type=int, default=32)
     ap.add_argument("--device", default="cuda")
     a = ap.parse_args(argv)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:   # one process per GPU; the process group is created before anything touches the device
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if a.device.startswith("cuda"):
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(local)
+            a.device = f"cuda:{local}"
+            dist.init_process_group("nccl", device_id=torch.device(a.device))
+        else:
+            dist.init_process_group("gloo")
     from src.models import get_model
     model = get_model("AmodalDAv2", guide_type=a.guide_type, loss_stategy=a.loss_stategy, encoder=a.encoder, pretrained=False)
     if a.trained_checkpoint:
@@ -124,11 +165,15 @@ def main(argv=None):
     model = model.eval().to(a.device)
     ids = sample_ids(a.occ_image_dir, a.split_file)
     metrics = run(model, ids, a.occ_image_dir, a.whole_mask_dir, a.observation_depth_dir, a.output_dir, a.gt_depth_dir, a.batch_size, a.device)
-    if metrics:
+    if metrics and rank == 0:
         with open(os.path.join(a.output_dir, "metrics.json"), "w") as f:
             json.dump(metrics, f, indent=1)
         print(json.dumps(metrics))
-    print(f"wrote {len(ids)} depth maps to {os.path.join(a.output_dir, 'amodal_depth')}")
+    if rank == 0:
+        print(f"wrote {len(ids)} depth maps to {os.path.join(a.output_dir, 'amodal_depth')}" + (f" ({world} ranks)" if world > 1 else ""))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

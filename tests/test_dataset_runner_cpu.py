@@ -39,6 +39,12 @@ class _FakeModel:
         return (observation + 1) / 2 * 0.5 + 0.25      # [B,1,518,518] in (0,1)
 
 
+def _oracle_evaluate(pred, gt, mask):
+    p, g, m = pred.numpy(), gt.numpy(), mask.numpy()
+    al = np.stack([MO.align_depth_least_square(g[b], p[b], m[b])[0] for b in range(p.shape[0])])
+    return MO.depth_metrics(np.clip(al, 1e-3, 1.0), g, m)
+
+
 def test_runner_end_to_end(tmp_path):
     rng = np.random.default_rng(0)
     ids = ["101", "102", "103"]

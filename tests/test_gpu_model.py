@@ -94,6 +94,33 @@ def test_hip_forward_matches_oracle_full_map_and_batch_invariance(hip):
     assert torch.equal(one[0], out[1]), "HIP path is not batch invariant"
 
 
+def test_raw_vitg_1022_batch8_config5(hip):
+    """BASELINE config 5 at its full size: raw ViT-G, 8 x 1022 x 1022 (73 x 73 patches, N = 5330 tokens, bicubic pos-embed).  Size-
+    independent properties: shape, finiteness, non-negativity (ReLU head), batch invariance against single-image runs of two
+    of the images, and the B = 1 reference golden (tests/golden/raw_vitg_1022.npz) reproduced by the same model object."""
+    gold, meta = load_golden("raw_vitg_1022")
+    case = meta["case"]
+    model = build_product_model(case)
+    model.load_state_dict(synth_state_dict(model, meta), strict=True)
+    model = model.cuda()
+    x8, _, _, _ = case_inputs(dict(case, B=8, seed=11))
+    with torch.no_grad():
+        out = model(x8.cuda())
+        assert list(out.shape) == [8, 1022, 1022]
+        assert torch.isfinite(out).all() and float(out.min()) >= 0.0
+        assert float(out.std()) > 0.1
+        for b in (0, 5):
+            one = model(x8[b:b + 1].cuda())
+            err = rel_l1(one[0], out[b])
+            assert err < 1e-6, f"image {b}: batch of 8 differs from the single-image run by {err:.2e}"
+        x1, _, _, _ = case_inputs(case)
+        o1 = model(x1.cuda()).cpu()
+    st = case["stride"]
+    err = rel_l1(o1[..., ::st, ::st], gold)
+    print(f"raw_vitg_1022 (after the batch-8 run): rel-L1 vs reference golden = {err:.3e}")
+    assert err <= TOL
+
+
 def test_state_dict_reload_repacks(hip):
     """load_state_dict after a forward must invalidate the packed operand copies."""
     _, meta = load_golden("vits_g_mask")
@@ -157,7 +184,9 @@ def test_raw_swiglu_module_path(hip):
 
 
 def test_infer_cli_end_to_end_on_gpu(hip, tmp_path):
-    """python infer.py ... on the GPU with (synthetic-weight) ViT-S models: both reference-named PNGs are written."""
+    """python infer.py ... on the GPU with (synthetic-weight) ViT-S models: both reference-named PNGs are written, and their
+    pixels agree with the same CLI pipeline driven by the fp32 CPU oracle (same weights, infer.infer_single_image with
+    device='cpu'): <= 1 grey level on >= 99 % of the pixels of both renders."""
     import os
     import subprocess
     import sys
@@ -165,18 +194,42 @@ def test_infer_cli_end_to_end_on_gpu(hip, tmp_path):
     import numpy as np
     from PIL import Image
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import infer
+    from oracle import dav2_oracle as O
     rng = np.random.default_rng(1)
-    Image.fromarray((rng.random((90, 120, 3)) * 255).astype(np.uint8)).save(tmp_path / "img.jpg")
+    yy, xx = np.mgrid[0:90, 0:120]
+    img = np.stack([(np.sin(xx / 17.0) * 0.5 + 0.5) * 255, (np.cos(yy / 11.0) * 0.5 + 0.5) * 255, (xx + yy) / 210.0 * 255], -1)
+    img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+    Image.fromarray(img).save(tmp_path / "img.png")
     m = np.zeros((64, 64), dtype=np.uint8)
     m[20:50, 10:40] = 255
     Image.fromarray(m).save(tmp_path / "img_mask.png")
-    r = subprocess.run([sys.executable, os.path.join(root, "infer.py"), "--input_image_path", str(tmp_path / "img.jpg"),
+    r = subprocess.run([sys.executable, os.path.join(root, "infer.py"), "--input_image_path", str(tmp_path / "img.png"),
                         "--input_mask_path", str(tmp_path / "img_mask.png"), "--output_folder", str(tmp_path / "out"),
                         "--raw_encoder", "vits", "--amodal_encoder", "vits"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+
+    # the same pipeline with the CPU oracle standing in for both networks (synthetic weights = what the CLI falls back to)
+    raw_case = dict(kind="raw", encoder="vits", features=64, out_channels=[48, 96, 192, 384])
+    am_case = dict(kind="amodal", encoder="vits", guide_type="mask+observation", loss="entire_target_object")
+    raw_sd = synth_state_dict(build_product_model(raw_case))
+    am_sd = synth_state_dict(build_product_model(am_case))
+
+    def oracle_raw(x):
+        return O.raw_forward(raw_sd, "vits", x)
+
+    def oracle_amodal(x, guide_rgb=None, guide_mask=None, observation=None):
+        return O.amodal_forward(am_sd, "vits", "mask+observation", "entire_target_object", x, None, guide_mask, observation)
+
+    infer.infer_single_image(str(tmp_path / "img.png"), str(tmp_path / "img_mask.png"), str(tmp_path / "ref"), oracle_raw, oracle_amodal, device="cpu")
     for suffix in ("raw_depth_rendered", "amodal_depth_rendered"):
-        im = Image.open(tmp_path / "out" / f"img_{suffix}.png")
-        assert im.size == (120, 90)
+        got = np.asarray(Image.open(tmp_path / "out" / f"img_{suffix}.png")).astype(np.int32)
+        want = np.asarray(Image.open(tmp_path / "ref" / f"img_{suffix}.png")).astype(np.int32)
+        assert got.shape == want.shape == (90, 120, 3)
+        close = (np.abs(got - want).max(-1) <= 1).mean()
+        print(f"{suffix}: {100 * close:.2f} % of the pixels within 1 grey level of the oracle-driven render (max diff {np.abs(got - want).max()})")
+        assert close >= 0.99, f"{suffix}: only {100 * close:.2f} % of the pixels within 1 LSB"
 
 
 def test_on_device_pipeline_matches_host_composition(hip):

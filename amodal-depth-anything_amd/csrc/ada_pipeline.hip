@@ -83,7 +83,43 @@ __global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ am
     out[img + (long)y * W + x] = v;
 }
 
+// Overlap-blend of tile predictions into the full-resolution map (tiled inference for inputs larger than the network's 518 x 518).
+// Tile t of image b covers rows oy[t] .. oy[t] + th - 1, columns ox[t] .. ox[t] + tw - 1 and carries the separable feather weight
+// w(i, n) = min(i + 1, n - i, ramp) / ramp along each axis (1 in the tile interior, a linear ramp over the `ramp` outermost
+// pixels), so two overlapping tiles cross-fade linearly and a pixel covered by a single tile keeps that tile's value:
+//     out(b, y, x) = sum_t w_t(y, x) * tile_t(y - oy_t, x - ox_t) / sum_t w_t(y, x)
+// One thread per output pixel, gathering from the (at most four) tiles that cover it.
+__global__ __launch_bounds__(256) void tile_blend_kernel(const float* __restrict__ tiles, int T, int th, int tw, const int* __restrict__ oy,
+                                                         const int* __restrict__ ox, int H, int W, int ramp, float* __restrict__ out) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    const int y = blockIdx.y, b = blockIdx.z;
+    const float inv = 1.0f / (float)ramp;
+    float acc = 0.0f, wsum = 0.0f;
+    for (int t = 0; t < T; ++t) {
+        const int ty = y - oy[t], tx = x - ox[t];
+        if (ty < 0 || ty >= th || tx < 0 || tx >= tw) continue;
+        const float wy = (float)min(min(ty + 1, th - ty), ramp) * inv;
+        const float wx = (float)min(min(tx + 1, tw - tx), ramp) * inv;
+        const float w = wy * wx;
+        acc += w * tiles[(((long)b * T + t) * th + ty) * tw + tx];
+        wsum += w;
+    }
+    out[((long)b * H + y) * W + x] = acc / wsum;
+}
+
 }  // namespace
+
+extern "C" int ada_tile_blend_fwd(const float* tiles, int32_t batch, int32_t n_tiles, int32_t tile_h, int32_t tile_w, const int32_t* origin_y,
+                                  const int32_t* origin_x, int32_t height, int32_t width, int32_t ramp, float* out, void* stream) {
+    ADA_REQUIRE(tiles && origin_y && origin_x && out, ADA_EINVAL, "ada_tile_blend_fwd: null pointer");
+    ADA_REQUIRE(batch > 0 && batch <= 65535 && n_tiles > 0 && tile_h > 0 && tile_w > 0 && height >= tile_h && width >= tile_w && height <= 65535,
+                ADA_EINVAL, "ada_tile_blend_fwd: bad shape B=%d T=%d tile=%dx%d image=%dx%d", batch, n_tiles, tile_h, tile_w, height, width);
+    ADA_REQUIRE(ramp >= 1 && 2 * ramp <= tile_h && 2 * ramp <= tile_w, ADA_EINVAL, "ada_tile_blend_fwd: ramp=%d must be in [1, tile/2]", ramp);
+    hipLaunchKernelGGL(tile_blend_kernel, dim3((width + 255) / 256, height, batch), dim3(256), 0, (hipStream_t)stream, tiles, n_tiles, tile_h,
+                       tile_w, origin_y, origin_x, height, width, ramp, out);
+    return ada_check_launch("ada_tile_blend_fwd");
+}
 
 extern "C" int ada_minmax_fwd(const float* in, int32_t batch, int64_t n_per_image, float* minmax, void* stream) {
     ADA_REQUIRE(in && minmax, ADA_EINVAL, "ada_minmax_fwd: null pointer");

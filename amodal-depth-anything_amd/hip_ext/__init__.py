@@ -28,7 +28,7 @@ ACT_NONE, ACT_SIGMOID, ACT_RELU = 0, 1, 2
 EXPORTS = (
     "ada_abi_version", "ada_operand_dtype", "ada_last_error", "ada_igemm", "ada_attention_fwd",
     "ada_layernorm_fwd", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
-    "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd",
+    "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd",
     "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
     "ada_debug_set_timestamps", "ada_debug_set_attention_variant", "ada_debug_set_attention_profile",
 )
@@ -109,6 +109,8 @@ def load(path: Optional[str] = None):
     lib.ada_normalize_fwd.restype = c_int
     lib.ada_blend_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
     lib.ada_blend_fwd.restype = c_int
+    lib.ada_tile_blend_fwd.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
+    lib.ada_tile_blend_fwd.restype = c_int
     lib.ada_depth_eval_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_float, c_float, c_void_p, c_void_p]
     lib.ada_depth_eval_fwd.restype = c_int
     for name in ("ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_set_attention_variant"):
@@ -277,6 +279,14 @@ def blend(amodal, base, mask, out):
     B, H, W = amodal.shape[0], amodal.shape[-2], amodal.shape[-1]
     _check(load().ada_blend_fwd(_dev(amodal, "amodal", torch.float32), _dev(base, "base", torch.float32), _dev(mask, "mask", torch.float32),
                                 B, H, W, _dev(out, "out", torch.float32), _stream()), "ada_blend_fwd")
+
+
+def tile_blend(tiles, origin_y, origin_x, height, width, ramp, out):
+    """tiles fp32 [B, T, th, tw]; origin_y / origin_x int32 [T] on the device; out fp32 [B, height, width] (ada_tile_blend_fwd)."""
+    B, T, th, tw = tiles.shape
+    _check(load().ada_tile_blend_fwd(_dev(tiles, "tiles", torch.float32), B, T, th, tw, _dev(origin_y, "origin_y", torch.int32),
+                                     _dev(origin_x, "origin_x", torch.int32), height, width, ramp, _dev(out, "out", torch.float32), _stream()),
+           "ada_tile_blend_fwd")
 
 
 def depth_eval(pred, gt, mask=None, scale_shift=None, clip=None) -> torch.Tensor:

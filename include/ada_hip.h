@@ -239,6 +239,18 @@ int ada_normalize_fwd(const float* in, const float* minmax, int32_t batch, int64
 int ada_blend_fwd(const float* amodal, const float* base, const float* mask, int32_t batch, int32_t height,
                   int32_t width, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Tiled inference for inputs larger than the network's native 518 x 518 (the reference squashes every
+ * input to 518 x 518, infer.py:17,84).  ada_tile_blend_fwd merges the per-tile predictions:
+ *   tiles     fp32 [B, T, tile_h, tile_w]; tile t covers rows origin_y[t].. and columns origin_x[t].. of the full map
+ *             (origin_* are DEVICE int32 [T]); every output pixel must be covered by at least one tile
+ *   weight    separable feather min(i + 1, n - i, ramp) / ramp per axis: linear cross-fade over `ramp` pixels in overlaps
+ *   out       fp32 [B, height, width] = sum_t w_t tile_t / sum_t w_t
+ * ---------------------------------------------------------------------------------------- */
+int ada_tile_blend_fwd(const float* tiles, int32_t batch, int32_t n_tiles, int32_t tile_h, int32_t tile_w,
+                       const int32_t* origin_y, const int32_t* origin_x, int32_t height, int32_t width,
+                       int32_t ramp, float* out, void* stream);
+
 /* Hardware self-test used by the GPU test-suite: checks the MFMA / LDS-transpose fragment layouts the
  * kernels assume against a scalar computation on the device.  Returns 0 when they hold,
  * a positive bit mask of failed probes otherwise.  scratch: >= 1 MiB of device memory. */

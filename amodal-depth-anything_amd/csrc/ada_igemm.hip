@@ -55,6 +55,10 @@ struct IgemmDev {
     int map_h, map_w;
     FastDiv dMapW, dMapHW;
     int shuffle_s, shuffle_c;
+    const float* ln_stats;    // EP_LNFOLD: per-row (mean, rstd) of the un-normalised A operand
+    const float* ln_colsum;   // EP_LNFOLD: per-column sum of the (gain-folded) weights
+    float* rowstat_out;       // EP_ROWSTATS: partial (sum, sum of squares) of the fp32 output per row and 64-column group
+    int rowstat_groups;       // N / 64
     int split_seg;   // > 0: the op-typed output is written as [hi | lo | hi] in three column segments of this width (split precision)
     FastDiv dShC, dShS;
     const float* tail_w;
@@ -158,6 +162,30 @@ ADA_DEV void store_op8(const IgemmDev& p, op_t* dst, float4 v0, float4 v1) {
         *(opx8*)(dst + p.split_seg) = l;
         *(opx8*)(dst + 2 * p.split_seg) = o;
     }
+}
+
+// LayerNorm folded into the contraction that consumes it (ADA_EP_LNFOLD): the A operand is the UN-normalised row x (operand-typed copy
+// written by the producing epilogue), the weights carry the LayerNorm gain, and with s_n = sum_k W'[n,k], c_n = bias_n + sum_k beta_k W[n,k]
+//     LN(x) W^T + bias  =  rstd * (x W'^T - mean * s) + c
+// so the stand-alone LayerNorm launch (read 4 B + write 2 B per element of the whole token matrix) disappears.
+ADA_DEV float4 ln_fold4(float4 acc, float mu, float rstd, float4 s, float4 c) {
+    float4 v;
+    v.x = (acc.x - mu * s.x) * rstd + c.x; v.y = (acc.y - mu * s.y) * rstd + c.y;
+    v.z = (acc.z - mu * s.z) * rstd + c.z; v.w = (acc.w - mu * s.w) * rstd + c.w;
+    return v;
+}
+// Row statistics for the NEXT LayerNorm, taken from the values this epilogue writes to the fp32 residual stream (ADA_EP_ROWSTATS): the 16
+// lanes that hold one row's 64 columns of a wave tile reduce (sum, sum of squares) with xor shuffles and lane 0 of the group stores
+// the pair -- one slot per (row, 64-column group), no atomics, so the result is bit-reproducible.
+ADA_DEV void rowstat_store(const IgemmDev& p, float4 v, long row, int group, bool leader, bool valid) {
+    float s1 = (v.x + v.y) + (v.z + v.w);
+    float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (leader && valid) *(float2*)(p.rowstat_out + (row * p.rowstat_groups + group) * 2) = make_float2(s1, s2);
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, bool PHASED = false>
@@ -651,16 +679,23 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             const int cg = lane % CG, rsub = lane / CG;
             const bool relu = (flags & ADA_EP_RELU_OP) != 0;
             const long ld = p.ldo_op;
+            const bool lnfold = EPI != EPI_SHUFFLE && (flags & ADA_EP_LNFOLD) != 0;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int n = nwave + g * GW + 8 * cg;
-                float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, g0 = make_float4(1, 1, 1, 1), g1 = g0;
+                float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, g0 = make_float4(1, 1, 1, 1), g1 = g0, cs0 = b0, cs1 = b0;
                 if (has_bias) { b0 = *(const float4*)(p.bias + n); b1 = *(const float4*)(p.bias + n + 4); }
                 if (has_gamma) { g0 = *(const float4*)(p.gamma + n); g1 = *(const float4*)(p.gamma + n + 4); }
+                if (lnfold) { cs0 = *(const float4*)(p.ln_colsum + n); cs1 = *(const float4*)(p.ln_colsum + n + 4); }
                 op_t* dst = p.out_op + (long)(mbase + rsub) * ld + n;
                 const bool pad = p.map_op == ADA_MAP_PAD;
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
+                    float2 st[32 / RPI];
+                    if (lnfold) {   // (mean, rstd) of this lane's rows, requested before the transpose so they land behind it
+#pragma unroll
+                        for (int k = 0; k < 32 / RPI; ++k) st[k] = *(const float2*)(p.ln_stats + (long)(mbase + i * 32 + k * RPI + rsub) * 2);
+                    }
                     dump(i, g);
                     PadWalk walk;
                     if (pad) walk = pad_start(p, (uint32_t)(mbase + i * 32 + rsub));
@@ -669,8 +704,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                         const int row = k * RPI + rsub;
                         float4 v0 = *(const float4*)(slab + row * SW + 8 * cg);
                         float4 v1 = *(const float4*)(slab + row * SW + 8 * cg + 4);
-                        v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
-                        v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
+                        if (lnfold) {
+                            v0 = ln_fold4(v0, st[k].x, st[k].y, cs0, b0);
+                            v1 = ln_fold4(v1, st[k].x, st[k].y, cs1, b1);
+                        } else {
+                            v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
+                            v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
+                        }
                         if constexpr (EPI == EPI_GELU) {
                             v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
                             v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
@@ -747,6 +787,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                     }
                     v.x = v.x * gamma4.x + rcur[k].x; v.y = v.y * gamma4.y + rcur[k].y;
                     v.z = v.z * gamma4.z + rcur[k].z; v.w = v.w * gamma4.w + rcur[k].w;
+                    if (EPI != EPI_SHUFFLE && (flags & ADA_EP_ROWSTATS)) rowstat_store(p, v, mrow + k * RPI, (nwave + g * GW) >> 6, cg == 0, true);
                     if (p.out_f32) {
                         float4 w = v;
                         if (relu_f) {
@@ -787,10 +828,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             const int n = nwave + g * GW + 8 * cg;
             const bool nval = n < p.N;
             const bool nval2 = n + 4 < p.N;
-            float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, g0 = make_float4(1, 1, 1, 1), g1 = g0;
+            float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, g0 = make_float4(1, 1, 1, 1), g1 = g0, cs0 = b0, cs1 = b0;
+            const bool lnfold = EPI != EPI_SHUFFLE && (flags & ADA_EP_LNFOLD) != 0;
             if (flags & ADA_EP_BIAS) {
                 if (nval) b0 = *(const float4*)(p.bias + n);
                 if (nval2) b1 = *(const float4*)(p.bias + n + 4);
+            }
+            if (lnfold) {
+                if (nval) cs0 = *(const float4*)(p.ln_colsum + n);
+                if (nval2) cs1 = *(const float4*)(p.ln_colsum + n + 4);
             }
             if (flags & ADA_EP_GAMMA) {
                 if (nval) g0 = *(const float4*)(p.gamma + n);
@@ -811,8 +857,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                     const int m = mbase + i * 32 + row;
                     float4 v0 = *(const float4*)(slab + row * SW + 8 * cg);
                     float4 v1 = *(const float4*)(slab + row * SW + 8 * cg + 4);
-                    v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
-                    v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
+                    if (lnfold) {
+                        const float2 st = *(const float2*)(p.ln_stats + (long)(m < p.M ? m : p.M - 1) * 2);
+                        v0 = ln_fold4(v0, st.x, st.y, cs0, b0);
+                        v1 = ln_fold4(v1, st.x, st.y, cs1, b1);
+                    } else {
+                        v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
+                        v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
+                    }
                     if constexpr (EPI == EPI_GELU) {
                         v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
                         v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
@@ -917,6 +969,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 }
                 v.x = v.x * gamma4.x + rcur[k].x; v.y = v.y * gamma4.y + rcur[k].y;
                 v.z = v.z * gamma4.z + rcur[k].z; v.w = v.w * gamma4.w + rcur[k].w;
+                if (EPI != EPI_SHUFFLE && (flags & ADA_EP_ROWSTATS)) rowstat_store(p, v, (long)m, (nwave + g * GW) >> 6, cg == 0, m < p.M && nval);
                 if (m < p.M && nval) {
                     if (p.out_f32) {
                         const long frow = map_row(p, p.map_f32, (uint32_t)m);
@@ -1130,6 +1183,19 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
                     "ada_igemm: SHUFFLE needs N == s*s*c");
         ADA_REQUIRE(a->shuffle_c % 4 == 0 && !a->out_f32 && !(f & ADA_EP_GELU), ADA_EUNSUPPORTED, "ada_igemm: SHUFFLE needs c %% 4 == 0, operand output only");
     }
+    if (f & ADA_EP_LNFOLD) {
+        ADA_REQUIRE(a->ln_stats && a->ln_colsum && a->bias && (f & ADA_EP_BIAS), ADA_EINVAL, "ada_igemm: EP_LNFOLD needs ln_stats, ln_colsum and bias (the folded constant)");
+        ADA_REQUIRE(a->out_op && !a->out_f32 && !(f & (ADA_EP_RESIDUAL | ADA_EP_GAMMA)) && !tail && !swiglu && !shuffle && a->a_mode == ADA_A_PLAIN &&
+                    a->map_op == ADA_MAP_PLAIN && a->N % 8 == 0 && a->ldo_op % 8 == 0, ADA_EUNSUPPORTED,
+                    "ada_igemm: EP_LNFOLD supports plain linear layers with an operand-typed output (bias / GELU epilogues), N %% 8 == 0");
+        ADA_REQUIRE(((uintptr_t)a->ln_stats % 8) == 0 && ((uintptr_t)a->ln_colsum % 16) == 0, ADA_EINVAL, "ada_igemm: ln_stats / ln_colsum alignment");
+    }
+    if (f & ADA_EP_ROWSTATS) {
+        ADA_REQUIRE(a->rowstat_out && a->N % 64 == 0 && a->N >= 64 && !tail && !swiglu && !shuffle, ADA_EINVAL, "ada_igemm: EP_ROWSTATS needs rowstat_out and N %% 64 == 0");
+        ADA_REQUIRE((a->out_f32 || (f & ADA_EP_RESIDUAL)) && (!a->out_f32 || a->map_f32 == ADA_MAP_PLAIN) && a->res_row_mod == 0, ADA_EUNSUPPORTED,
+                    "ada_igemm: EP_ROWSTATS is implemented for the fp32 / residual epilogue with a plain row map");
+        ADA_REQUIRE(((uintptr_t)a->rowstat_out % 8) == 0, ADA_EINVAL, "ada_igemm: rowstat_out must be 8-byte aligned");
+    }
     if (a->split_seg != 0) {
         ADA_REQUIRE(a->out_op && a->split_seg > 0 && a->split_seg % 8 == 0 && !swiglu, ADA_EINVAL, "ada_igemm: split_seg needs out_op, a positive multiple of 8, no SwiGLU");
         const int cols = shuffle ? a->shuffle_c : a->N;
@@ -1159,6 +1225,8 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.dMapHW = make_fastdiv(token ? a->map_h : (a->map_h > 0 && a->map_w > 0 ? a->map_h * a->map_w : 1));
     d.shuffle_s = a->shuffle_s; d.shuffle_c = a->shuffle_c;
     d.split_seg = a->split_seg;
+    d.ln_stats = a->ln_stats; d.ln_colsum = a->ln_colsum;
+    d.rowstat_out = a->rowstat_out; d.rowstat_groups = a->N / 64;
     d.dShC = make_fastdiv(a->shuffle_c > 0 ? a->shuffle_c : 1);
     d.dShS = make_fastdiv(a->shuffle_s > 0 ? a->shuffle_s : 1);
     d.tail_w = a->tail_w; d.tail_b = a->tail_b; d.tail_act = a->tail_act;

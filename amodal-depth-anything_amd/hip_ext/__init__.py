@@ -18,16 +18,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
 # --- constants mirrored from include/ada_hip.h ------------------------------------------------
-ABI_VERSION = 2
+ABI_VERSION = 3
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 A_PLAIN, A_CONV3 = 0, 1
 MAP_PLAIN, MAP_PAD, MAP_TOKEN, MAP_SHUFFLE = 0, 1, 2, 3
 EP_BIAS, EP_GELU, EP_GAMMA, EP_RESIDUAL, EP_RELU_OP, EP_SWIGLU, EP_TAIL, EP_RELU_F32 = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40, 0x80
+EP_ROWSTATS, EP_LNFOLD = 0x100, 0x200
 ACT_NONE, ACT_SIGMOID, ACT_RELU = 0, 1, 2
 
 EXPORTS = (
     "ada_abi_version", "ada_operand_dtype", "ada_last_error", "ada_igemm", "ada_attention_fwd",
-    "ada_layernorm_fwd", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
+    "ada_rowstats_finalize", "ada_layernorm_fwd", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
     "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd",
     "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
     "ada_debug_set_timestamps", "ada_debug_set_attention_variant", "ada_debug_set_attention_profile",
@@ -50,7 +51,8 @@ class IgemmArgs(ctypes.Structure):
         ("out_f32", c_void_p), ("ldo_f32", c_int64), ("map_f32", c_int32),
         ("out_op", c_void_p), ("ldo_op", c_int64), ("map_op", c_int32),
         ("map_h", c_int32), ("map_w", c_int32), ("shuffle_s", c_int32), ("shuffle_c", c_int32),
-        ("tail_w", c_void_p), ("tail_b", c_float), ("tail_act", c_int32), ("split_seg", c_int32),
+        ("tail_w", c_void_p), ("tail_b", c_float), ("tail_act", c_int32),
+        ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("rowstat_out", c_void_p), ("split_seg", c_int32),
     ]
 
 
@@ -88,6 +90,8 @@ def load(path: Optional[str] = None):
     lib.ada_last_error.restype = c_char_p
     lib.ada_igemm.argtypes = [ctypes.POINTER(IgemmArgs), c_void_p]
     lib.ada_igemm.restype = c_int
+    lib.ada_rowstats_finalize.argtypes = [c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p]
+    lib.ada_rowstats_finalize.restype = c_int
     lib.ada_attention_fwd.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]
     lib.ada_attention_fwd.restype = c_int
     lib.ada_layernorm_fwd.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_float,
@@ -193,7 +197,8 @@ def set_timer(t: Optional[KernelTimer]):
 # ------------------------------------------------------------------------------------------------
 def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=None, gamma=None, res=None, ldr=0,
           res_row_mod=0, res_row_off=0, flags=0, out_f32=None, ldo_f32=0, map_f32=MAP_PLAIN, out_op=None, ldo_op=0,
-          map_op=MAP_PLAIN, map_h=0, map_w=0, shuffle_s=0, shuffle_c=0, tail_w=None, tail_b=0.0, tail_act=ACT_NONE, split_seg=0):
+          map_op=MAP_PLAIN, map_h=0, map_w=0, shuffle_s=0, shuffle_c=0, tail_w=None, tail_b=0.0, tail_act=ACT_NONE, split_seg=0,
+          ln_stats=None, ln_colsum=None, rowstat_out=None):
     op = operand_dtype()
     a = IgemmArgs()
     a.M, a.N, a.K, a.a_mode = M, N, K, a_mode
@@ -210,6 +215,8 @@ def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=Non
     a.map_h, a.map_w, a.shuffle_s, a.shuffle_c = map_h, map_w, shuffle_s, shuffle_c
     a.tail_w, a.tail_b, a.tail_act = _opt(tail_w, "tail_w", torch.float32), tail_b, tail_act
     a.split_seg = split_seg
+    a.ln_stats, a.ln_colsum = _opt(ln_stats, "ln_stats", torch.float32), _opt(ln_colsum, "ln_colsum", torch.float32)
+    a.rowstat_out = _opt(rowstat_out, "rowstat_out", torch.float32)
     if _timer is not None:
         ev = _timer.start()
         _check(load().ada_igemm(ctypes.byref(a), _stream()), "ada_igemm")
@@ -218,6 +225,12 @@ def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=Non
         _check(load().ada_igemm(ctypes.byref(a), _stream()), "ada_igemm")
     if _tile_log is not None:
         _tile_log.append((M, N, K, load().ada_debug_last_tile()))
+
+
+def rowstats_finalize(partials: torch.Tensor, rows: int, groups: int, eps: float, stats: torch.Tensor):
+    """partials fp32 [rows, groups, 2] -> stats fp32 [rows, 2] = (mean, rstd) (ada_rowstats_finalize)."""
+    _check(load().ada_rowstats_finalize(_dev(partials, "partials", torch.float32), rows, groups, eps, _dev(stats, "stats", torch.float32), _stream()),
+           "ada_rowstats_finalize")
 
 
 def attention(qkv: torch.Tensor, out: torch.Tensor, batch: int, n_tokens: int, heads: int):

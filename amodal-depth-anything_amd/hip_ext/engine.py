@@ -23,14 +23,15 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn.functional as F
 
-from . import (A_CONV3, A_PLAIN, ACT_NONE, ACT_RELU, ACT_SIGMOID, EP_BIAS, EP_GAMMA, EP_GELU, EP_RELU_OP, EP_RESIDUAL,
-               EP_SWIGLU, EP_TAIL, MAP_PAD, MAP_PLAIN, MAP_SHUFFLE, MAP_TOKEN, HipExtError)
+from . import (A_CONV3, A_PLAIN, ACT_NONE, ACT_RELU, ACT_SIGMOID, EP_BIAS, EP_GAMMA, EP_GELU, EP_LNFOLD, EP_RELU_OP, EP_RESIDUAL,
+               EP_ROWSTATS, EP_SWIGLU, EP_TAIL, MAP_PAD, MAP_PLAIN, MAP_SHUFFLE, MAP_TOKEN, HipExtError)
 from . import attention as k_attention
 from . import bilinear as k_bilinear
 from . import igemm as k_igemm
 from . import layernorm as k_layernorm
 from . import operand_dtype
 from . import patchify as k_patchify
+from . import rowstats_finalize as k_rowstats_finalize
 from . import write_cls as k_write_cls
 
 PATCH = 14
@@ -54,7 +55,8 @@ class PackedWeights:
     """Operand-typed copies of the parameters, laid out for the kernels.  ``sd``: name -> fp32 CUDA tensor
     with the *raw* model's key names (``pretrained.*``, ``depth_head.*``)."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], encoder: str, guided: bool, amodal_head: bool, split_head: bool = False):
+    def __init__(self, sd: Dict[str, torch.Tensor], encoder: str, guided: bool, amodal_head: bool, split_head: bool = False,
+                 fold_ln: bool = False):
         op = operand_dtype()
         cfg = VIT[encoder]
         D = cfg["dim"]
@@ -64,6 +66,11 @@ class PackedWeights:
         # 3x the K evaluates x_hi w_hi + x_lo w_hi + x_hi w_lo (~fp32 operand accuracy).  Used where the head's operand rounding
         # is what limits parity: the unbounded-output models (raw ReLU / 'ssi' heads) and ViT-S.
         self.split_head = split_head
+        # fold_ln: the block LayerNorms (reference block.py:84,87) are folded into the qkv / fc1 contractions that consume them --
+        # gain into the weights, mean / rstd applied in the GEMM epilogue (ADA_EP_LNFOLD), row statistics produced by the proj / fc2
+        # epilogue that writes the residual stream (ADA_EP_ROWSTATS): no stand-alone LayerNorm launch between the GEMMs of a block
+        # (only the very first LayerNorm of the encoder, whose input comes from the patch embedding, runs as a kernel).  MLP blocks only.
+        self.fold_ln = bool(fold_ln) and cfg["ffn"] == "mlp"
         self.dim, self.depth, self.heads, self.ffn = D, cfg["depth"], cfg["heads"], cfg["ffn"]
 
         def f32(name):
@@ -131,6 +138,14 @@ class PackedWeights:
                 blk.update(fc1_w=lin(f32(b + "mlp.fc1.weight")), fc1_b=f32(b + "mlp.fc1.bias"),
                            fc2_w=lin(f32(b + "mlp.fc2.weight")), fc2_b=f32(b + "mlp.fc2.bias"))
                 blk["hidden"] = blk["fc1_w"].shape[0]
+                if self.fold_ln:
+                    def fold(wmat, bias, g, beta):   # LN(x) W^T + b = rstd (x W'^T - mean s) + c
+                        wf = lin(wmat * g[None, :])
+                        return wf, wf.float().sum(1).contiguous(), (bias + wmat @ beta).contiguous()
+                    fw = f32(b + "mlp.fc1.weight")
+                    blk["fc1_wf"], blk["fc1_s"], blk["fc1_c"] = fold(fw, blk["fc1_b"], blk["ln2_w"], blk["ln2_b"])
+                    if i > 0:   # block 0's first LayerNorm reads the patch-embedding output: it stays a kernel
+                        blk["qkv_wf"], blk["qkv_s"], blk["qkv_c"] = fold(qw, qb, blk["ln1_w"], blk["ln1_b"])
             else:
                 w12, b12 = f32(b + "mlp.w12.weight"), f32(b + "mlp.w12.bias")
                 hid = w12.shape[0] // 2
@@ -234,7 +249,10 @@ class Workspace:
 
         self.a_pe = z(P, pw_.pe_k)
         self.x = z(T, D, dtype=torch.float32)
-        self.y = z(T, D)
+        self.y = z(T, D)     # LayerNorm output; with folded LayerNorms: the operand-typed copy of the residual stream itself
+        if pw_.fold_ln:
+            self.part = z(T, D // 64, 2, dtype=torch.float32)    # per-row partial (sum, sum of squares), one slot per 64 columns
+            self.stats = z(T, 2, dtype=torch.float32)            # (mean, rstd) per row
         self.qkv = z(T, 3 * D)
         self.o = z(T, D)
         hidden = pw_.blocks[0]["hidden"]
@@ -327,24 +345,45 @@ class DepthEngine:
 
         # ---- transformer blocks ------------------------------------------------------------------
         taps = TAPS[w.encoder]
+        fold = w.fold_ln
+        G = D // 64
         for i, blk in enumerate(w.blocks):
-            k_layernorm(ws.x, D, T, D, blk["ln1_w"], blk["ln1_b"], LN_EPS, out_op=ws.y, ld_op=D)
-            k_igemm(M=T, N=3 * D, K=D, A=ws.y, lda=D, W=blk["qkv_w"], bias=blk["qkv_b"], flags=EP_BIAS, out_op=ws.qkv, ldo_op=3 * D)
-            k_attention(ws.qkv, ws.o, B, N, heads)
-            k_igemm(M=T, N=D, K=D, A=ws.o, lda=D, W=blk["proj_w"], bias=blk["proj_b"], gamma=blk["ls1"], res=ws.x, ldr=D,
-                    flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D)
-            k_layernorm(ws.x, D, T, D, blk["ln2_w"], blk["ln2_b"], LN_EPS, out_op=ws.y, ld_op=D)
-            hid = blk["hidden"]
-            if w.ffn == "mlp":
-                k_igemm(M=T, N=hid, K=D, A=ws.y, lda=D, W=blk["fc1_w"], bias=blk["fc1_b"], flags=EP_BIAS | EP_GELU,
-                        out_op=ws.hd, ldo_op=hid)
-                k_igemm(M=T, N=D, K=hid, A=ws.hd, lda=hid, W=blk["fc2_w"], bias=blk["fc2_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
-                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D)
+            last = i == len(w.blocks) - 1
+            if fold and i > 0:   # x arrives as the operand-typed copy written by the previous fc2 epilogue, with its row statistics
+                k_igemm(M=T, N=3 * D, K=D, A=ws.y, lda=D, W=blk["qkv_wf"], bias=blk["qkv_c"], ln_stats=ws.stats, ln_colsum=blk["qkv_s"],
+                        flags=EP_BIAS | EP_LNFOLD, out_op=ws.qkv, ldo_op=3 * D)
             else:
-                k_igemm(M=T, N=2 * hid, K=D, A=ws.y, lda=D, W=blk["w12_w"], bias=blk["w12_b"], flags=EP_BIAS | EP_SWIGLU,
-                        out_op=ws.hd, ldo_op=hid)
-                k_igemm(M=T, N=D, K=hid, A=ws.hd, lda=hid, W=blk["w3_w"], bias=blk["w3_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
+                k_layernorm(ws.x, D, T, D, blk["ln1_w"], blk["ln1_b"], LN_EPS, out_op=ws.y, ld_op=D)
+                k_igemm(M=T, N=3 * D, K=D, A=ws.y, lda=D, W=blk["qkv_w"], bias=blk["qkv_b"], flags=EP_BIAS, out_op=ws.qkv, ldo_op=3 * D)
+            k_attention(ws.qkv, ws.o, B, N, heads)
+            hid = blk["hidden"]
+            if fold:
+                k_igemm(M=T, N=D, K=D, A=ws.o, lda=D, W=blk["proj_w"], bias=blk["proj_b"], gamma=blk["ls1"], res=ws.x, ldr=D,
+                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL | EP_ROWSTATS, out_f32=ws.x, ldo_f32=D, out_op=ws.y, ldo_op=D, rowstat_out=ws.part)
+                k_rowstats_finalize(ws.part, T, G, LN_EPS, ws.stats)
+                k_igemm(M=T, N=hid, K=D, A=ws.y, lda=D, W=blk["fc1_wf"], bias=blk["fc1_c"], ln_stats=ws.stats, ln_colsum=blk["fc1_s"],
+                        flags=EP_BIAS | EP_GELU | EP_LNFOLD, out_op=ws.hd, ldo_op=hid)
+                if last:
+                    k_igemm(M=T, N=D, K=hid, A=ws.hd, lda=hid, W=blk["fc2_w"], bias=blk["fc2_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
+                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D)
+                else:
+                    k_igemm(M=T, N=D, K=hid, A=ws.hd, lda=hid, W=blk["fc2_w"], bias=blk["fc2_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
+                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL | EP_ROWSTATS, out_f32=ws.x, ldo_f32=D, out_op=ws.y, ldo_op=D, rowstat_out=ws.part)
+                    k_rowstats_finalize(ws.part, T, G, LN_EPS, ws.stats)
+            else:
+                k_igemm(M=T, N=D, K=D, A=ws.o, lda=D, W=blk["proj_w"], bias=blk["proj_b"], gamma=blk["ls1"], res=ws.x, ldr=D,
                         flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D)
+                k_layernorm(ws.x, D, T, D, blk["ln2_w"], blk["ln2_b"], LN_EPS, out_op=ws.y, ld_op=D)
+                if w.ffn == "mlp":
+                    k_igemm(M=T, N=hid, K=D, A=ws.y, lda=D, W=blk["fc1_w"], bias=blk["fc1_b"], flags=EP_BIAS | EP_GELU,
+                            out_op=ws.hd, ldo_op=hid)
+                    k_igemm(M=T, N=D, K=hid, A=ws.hd, lda=hid, W=blk["fc2_w"], bias=blk["fc2_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
+                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D)
+                else:
+                    k_igemm(M=T, N=2 * hid, K=D, A=ws.y, lda=D, W=blk["w12_w"], bias=blk["w12_b"], flags=EP_BIAS | EP_SWIGLU,
+                            out_op=ws.hd, ldo_op=hid)
+                    k_igemm(M=T, N=D, K=hid, A=ws.hd, lda=hid, W=blk["w3_w"], bias=blk["w3_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
+                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D)
             if i in taps:  # shared final LayerNorm on the tap, cls row dropped (dinov2.py:337-340)
                 tap = ws.taps[taps.index(i)]
                 k_layernorm(ws.x, D, P, D, w.norm_w, w.norm_b, LN_EPS, group_in=N, skip=1, out_op=tap, ld_op=tap.shape[1],

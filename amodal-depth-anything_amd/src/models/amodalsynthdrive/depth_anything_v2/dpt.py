@@ -102,13 +102,22 @@ class DPTHead(nn.Module):
         return HF.conv_tail(out, c0.weight, c0.bias, c2.weight, c2.bias, self.final_act)
 
 
+import os as _os
+
+# Folding the block LayerNorms into qkv / fc1 (PackedWeights.fold_ln) is built and parity-tested but OFF by default: on MI355X at
+# ViT-L bs=32 it removes 47 LayerNorm launches (-2.0 ms) and adds 2.3 ms to the GEMM epilogues that take over their work (the extra
+# operand-typed store of the residual stream, the row-statistics shuffles, the per-row rescale), with 7 % more parity error
+# (profiles/r02_e_layernorm_fold_ab.txt).  ADA_FOLD_LN=1 or ``module.fold_layernorm = True`` turns it on.
+_FOLD_LN_DEFAULT = _os.environ.get("ADA_FOLD_LN", "0") == "1"
+
+
 class _EngineMixin:
     """Lazily builds / refreshes the packed weights + launch plan whenever a parameter changes."""
 
     def _engine(self):
         from hip_ext.engine import DepthEngine, PackedWeights
         params = [(k, v) for k, v in self.state_dict(keep_vars=True).items()]
-        stamp = tuple((v.data_ptr(), v._version) for _, v in params) + (getattr(self, "head_precision", "auto"),)
+        stamp = tuple((v.data_ptr(), v._version) for _, v in params) + (getattr(self, "head_precision", "auto"), getattr(self, "fold_layernorm", _FOLD_LN_DEFAULT))
         if getattr(self, "_engine_stamp", None) != stamp:
             sd = {k: v.detach() for k, v in params}
             # Head precision policy ("auto"): the DPT head runs in split precision (3x its MACs) where its fp16 operand rounding
@@ -118,7 +127,7 @@ class _EngineMixin:
             mode = getattr(self, "head_precision", "auto")
             split = mode == "split" or (mode == "auto" and (self.depth_head.final_act != "sigmoid" or self.encoder == "vits"))
             pw = PackedWeights(sd, self.encoder, guided=self.pretrained.has_guidance, amodal_head=hasattr(self.depth_head, "input_projection"),
-                               split_head=split)
+                               split_head=split, fold_ln=bool(getattr(self, "fold_layernorm", _FOLD_LN_DEFAULT)))
             object.__setattr__(self, "_engine_obj", DepthEngine(pw, self.depth_head.final_act, bool(getattr(self, "normalise_input", False))))
             object.__setattr__(self, "_engine_stamp", stamp)
         return self._engine_obj

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADA_ABI_VERSION 2
+#define ADA_ABI_VERSION 3
 
 /* status codes */
 #define ADA_OK 0
@@ -91,6 +91,10 @@ const char* ada_last_error(void);
 #define ADA_EP_SWIGLU 0x20   /* columns come in (x1, x2) 32-wide groups: out = silu(x1) * x2 */
 #define ADA_EP_TAIL 0x40     /* v = relu(v); d = sum_n v*tail_w[n] + tail_b; out_f32[m] = act(d) */
 #define ADA_EP_RELU_F32 0x80 /* ReLU applied to the fp32 output as well */
+#define ADA_EP_ROWSTATS 0x100 /* also store per-row partial (sum, sum of squares) of the fp32 result: rowstat_out */
+#define ADA_EP_LNFOLD 0x200  /* A is the UN-normalised row, W carries the LayerNorm gain:
+                                v = rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n]   (block.py:84,87 folded into
+                                attention.py:51 / mlp.py:36; see ada_rowstats_finalize) */
 
 /* tail activations */
 #define ADA_ACT_NONE 0
@@ -124,11 +128,19 @@ typedef struct ada_igemm_args {
     const float* tail_w;    /* TAIL: [N] fp32 */
     float tail_b;
     int32_t tail_act;
+    const float* ln_stats;  /* LNFOLD: fp32 [M, 2] = (mean, rstd) per row (ada_rowstats_finalize) */
+    const float* ln_colsum; /* LNFOLD: fp32 [N], sum over k of the operand-typed, gain-folded weights W'[n, k] */
+    float* rowstat_out;     /* ROWSTATS: fp32 [M, N/64, 2], (sum, sum of squares) of the fp32 result over each 64-column group */
     int32_t split_seg;      /* > 0: split-precision op output -- out_op receives [hi | lo | hi] in three column segments of
                                split_seg elements (hi = round(v), lo = round(v - hi)); 0 = plain */
 } ada_igemm_args;
 
 int ada_igemm(const ada_igemm_args* args, void* stream);
+
+/* Finishes the row statistics an ADA_EP_ROWSTATS epilogue left behind: partials fp32 [rows, groups, 2] (sum, sum of squares
+ * per 64-column group) -> stats fp32 [rows, 2] = (mean, 1 / sqrt(var + eps)) over dim = 64 * groups columns, biased variance
+ * (nn.LayerNorm, DA2/dinov2_layers/block.py:84,87).  The consumer is an ADA_EP_LNFOLD contraction. */
+int ada_rowstats_finalize(const float* partials, int32_t rows, int32_t groups, float eps, float* stats, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused scaled-dot-product attention, head_dim 64 (all of ViT-S/B/L/G):

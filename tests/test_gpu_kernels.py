@@ -736,3 +736,58 @@ def test_igemm_split_output_plain_pad_shuffle(hip, forced_tile, cfg):
               map_h=5, map_w=6, shuffle_s=s_, shuffle_c=Co, split_seg=segc)
     ref = F.conv_transpose2d(xs, wt, stride=s_).permute(0, 2, 3, 1)
     _check_split(o[:, 1:-1, 1:-1], ref, Co, segc, op, f"igemm split shuffle cfg {cfg}", exact=False)
+
+
+# =====================================================================================================================
+# LayerNorm folded into the consuming contraction (ADA_EP_LNFOLD) + row statistics from the producing epilogue (ADA_EP_ROWSTATS)
+# =====================================================================================================================
+@pytest.mark.parametrize("cfg", [-1, 3, 4, 1, 2])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_igemm_layernorm_fold_pipeline(hip, forced_tile, cfg, gelu):
+    """x_new = x + (A W_p^T + b_p) * ls  (producer: fp32 residual stream, operand-typed copy, row statistics)  ->  finalize  ->
+    y = act(LN(x_new) W^T + b)  (consumer with the gain folded into W): against the same thing computed with torch in fp32."""
+    op = _op(hip)
+    if cfg >= 0:
+        forced_tile(cfg, 4)
+    M, D, Kp, N = 3 * 256 + 70, 256, 128, 320
+    A = _rand(M, Kp, seed=401).to(op).to(DEV)
+    Wp = (_rand(D, Kp, seed=402) * Kp ** -0.5).to(op).to(DEV)
+    bp, ls = _rand(D, seed=403).to(DEV), (_rand(D, seed=404) * 0.3 + 1).to(DEV)
+    x = (_rand(M, D, seed=405) * 2 + 0.7).to(DEV)           # rows with a non-zero mean
+    x_ref = x.cpu() + (A.float().cpu() @ Wp.float().cpu().T + bp.cpu()) * ls.cpu()
+    xh = torch.zeros(M, D, dtype=op, device=DEV)
+    part = torch.full((M, D // 64, 2), float("nan"), device=DEV)
+    hip.igemm(M=M, N=D, K=Kp, A=A, lda=Kp, W=Wp, bias=bp, gamma=ls, res=x, ldr=D, flags=hip.EP_BIAS | hip.EP_GAMMA | hip.EP_RESIDUAL | hip.EP_ROWSTATS,
+              out_f32=x, ldo_f32=D, out_op=xh, ldo_op=D, rowstat_out=part)
+    _close(x, x_ref, 3e-4, what="producer f32")
+    _close(xh, x_ref, 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="producer op copy")
+    xg = x.cpu().reshape(M, D // 64, 64)
+    _close(part[..., 0], xg.sum(-1), 2e-4, rtol=1e-5, what="row sums")
+    _close(part[..., 1], (xg * xg).sum(-1), 2e-3, rtol=1e-5, what="row sums of squares")
+    stats = torch.zeros(M, 2, device=DEV)
+    hip.rowstats_finalize(part, M, D // 64, 1e-6, stats)
+    mu, var = x.cpu().mean(1), x.cpu().var(1, unbiased=False)
+    _close(stats[:, 0], mu, 1e-5, rtol=1e-5, what="mean")
+    _close(stats[:, 1], (var + 1e-6).rsqrt(), 1e-5, rtol=2e-5, what="rstd")
+    # consumer
+    g, beta = (_rand(D, seed=406) * 0.2 + 1), _rand(D, seed=407) * 0.3
+    W = _rand(N, D, seed=408) * D ** -0.5
+    b = _rand(N, seed=409)
+    wf = (W * g[None, :]).to(op)
+    colsum = wf.float().sum(1).contiguous()
+    const = (b + W @ beta).contiguous()
+    out = torch.zeros(M, N, dtype=op, device=DEV)
+    hip.igemm(M=M, N=N, K=D, A=xh, lda=D, W=wf.to(DEV), bias=const.to(DEV), ln_stats=stats, ln_colsum=colsum.to(DEV),
+              flags=hip.EP_BIAS | hip.EP_LNFOLD | (hip.EP_GELU if gelu else 0), out_op=out, ldo_op=N)
+    ref = F.layer_norm(x.cpu(), (D,), g, beta, 1e-6) @ W.T + b
+    if gelu:
+        ref = F.gelu(ref)
+    # reference with the unfolded arithmetic on operand-rounded LN output (what the stand-alone LayerNorm path computes)
+    ref_unf = F.layer_norm(x.cpu(), (D,), g, beta, 1e-6).to(op).float() @ W.to(op).float().T + b
+    if gelu:
+        ref_unf = F.gelu(ref_unf)
+    e_fold = float((out.float().cpu() - ref).abs().mean() / ref.abs().mean())
+    e_unf = float((ref_unf.to(op).float() - ref).abs().mean() / ref.abs().mean())
+    print(f"cfg {cfg} gelu {gelu}: folded rel-L1 {e_fold:.2e} vs stand-alone LayerNorm path {e_unf:.2e}")
+    assert e_fold < max(2.0 * e_unf, 1e-3 if op == torch.float16 else 8e-3)
+    _close(out, ref, 6e-3, rtol=2e-2 if op == torch.bfloat16 else 6e-3, what="folded LN consumer")

@@ -94,6 +94,37 @@ def test_hip_forward_matches_oracle_full_map_and_batch_invariance(hip):
     assert torch.equal(one[0], out[1]), "HIP path is not batch invariant"
 
 
+def test_layernorm_folding_on_and_off(hip):
+    """The block LayerNorms folded into qkv / fc1 (default) and as stand-alone launches: both meet the bar on ViT-B at batch 8, and the
+    folded forward issues 2 * depth - 1 fewer LayerNorm launches."""
+    from hip_ext import engine as E
+    gold, meta = load_golden("vitb_518_b8")
+    case = meta["case"]
+    model = build_product_model(case)
+    model.load_state_dict(synth_state_dict(model, meta), strict=True)
+    x, grgb, mask, obs = case_inputs(case)
+    counts = {}
+    real_ln = E.k_layernorm
+    st = case["stride"]
+    try:
+        for fold in (True, False):
+            n = [0]
+
+            def counting(*a, _n=n, **k):
+                _n[0] += 1
+                return real_ln(*a, **k)
+            E.k_layernorm = counting
+            model.encoder.fold_layernorm = fold
+            out = _run_product(model, case, x, grgb, mask, obs)
+            counts[fold] = n[0]
+            err = rel_l1(out[..., ::st, ::st], gold)
+            print(f"vitb_518_b8 fold_layernorm={fold}: rel-L1 = {err:.3e}, {n[0]} LayerNorm launches")
+            assert err <= TOL
+    finally:
+        E.k_layernorm = real_ln
+    assert counts[False] - counts[True] == 2 * 12 - 1
+
+
 def test_raw_vitg_1022_batch8_config5(hip):
     """BASELINE config 5 at its full size: raw ViT-G, 8 x 1022 x 1022 (73 x 73 patches, N = 5330 tokens, bicubic pos-embed).  Size-
     independent properties: shape, finiteness, non-negativity (ReLU head), batch invariance against single-image runs of two

@@ -188,9 +188,13 @@ ADA_DEV void rowstat_store(const IgemmDev& p, float4 v, long row, int group, boo
     if (leader && valid) *(float2*)(p.rowstat_out + (row * p.rowstat_groups + group) * 2) = make_float2(s1, s2);
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, bool PHASED = false>
+// LOOP: main loop of the kernel -- 0 single-barrier loop (every tile shape), 1 phased ping-pong loop (256x256x64 tile with 2 x 4 waves).
+// (A third loop that loaded the weight fragments straight to registers -- LDS traffic 256 -> 160 KB per k-tile -- passed every test and
+// ran 30 % slower: fragment-shaped loads are expensive on the texture path.  profiles/r02_g_gemm_b_direct_ab.txt)
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, int LOOP = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && BM * BN == 256 * 256) ? 1 : 2) void igemm_kernel(IgemmDev p) {
-    static_assert(!PHASED || (BM == 256 && BN == 256 && BK == 64 && WAVES_M == 2 && WAVES_N == 4), "the phased main loop is written for the 256x256x64 tile, 2 x 4 waves");
+    constexpr bool PHASED = LOOP == 1;
+    static_assert(LOOP == 0 || (BM == 256 && BN == 256 && BK == 64 && WAVES_M == 2 && WAVES_N == 4), "the phased main loop is written for the 256x256x64 tile, 2 x 4 waves");
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int NT = NWAVES * 64;
     constexpr int TI = BM / (WAVES_M * 32);
@@ -1026,7 +1030,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
 static int g_group_override = 0;  // debug: force the column-group width (0 = model)
 static thread_local int g_last_tile = -1;   // tile configuration of the calling thread's most recent launch (ada_debug_last_tile)
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, bool PHASED = false>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, int LOOP = 0>
 int launch_cfg(IgemmDev& d, hipStream_t stream) {
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int SMEM = 2 * (BM + BN) * BK * 2;
@@ -1048,7 +1052,7 @@ int launch_cfg(IgemmDev& d, hipStream_t stream) {
         }
         d.group_n = g_group_override > 0 ? (g_group_override < d.tiles_n ? g_group_override : d.tiles_n) : gbest;
     }
-    auto kern = igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, EPI, PHASED>;
+    auto kern = igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, EPI, LOOP>;
     static std::once_flag attr_once;   // one per template instantiation; concurrent first calls are serialised
     std::call_once(attr_once, [&]() {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
@@ -1056,7 +1060,7 @@ int launch_cfg(IgemmDev& d, hipStream_t stream) {
         }
     });
     g_last_tile = (BM == 256 && BN == 32 ? 0 : BM == 128 && BN == 64 ? 1 : BM == 256 && BN == 128 ? 2 : BM == 256 && BN == 256 ? 3 :
-                   BM == 128 && BN == 128 ? 4 : BM == 128 && BN == 256 ? 5 : 7) + (PHASED ? 100 : 0);
+                   BM == 128 && BN == 128 ? 4 : BM == 128 && BN == 256 ? 5 : 7) + 100 * LOOP;
     const long nblk = (long)d.tiles_m * d.tiles_n;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), SMEM, stream, d);
     return ada_check_launch("ada_igemm");
@@ -1098,7 +1102,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
     if constexpr (EPI == EPI_SWIGLU) {
         if (cfg == 4 || cfg == 2) return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
         if (cfg == 5) return launch_cfg<128, 256, 32, 2, 2, EPI>(d, s);
-        if (d.variant >= 8) return launch_cfg<256, 256, 64, 2, 4, EPI, true>(d, s);
+        if (d.variant >= 8) return launch_cfg<256, 256, 64, 2, 4, EPI, 1>(d, s);
         return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
     } else if constexpr (EPI == EPI_TAIL) {
         return cfg == 0 ? launch_cfg<256, 32, 64, 4, 1, EPI>(d, s) : launch_cfg<128, 64, 64, 4, 1, EPI>(d, s);
@@ -1111,7 +1115,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
             case 5: return launch_cfg<128, 256, 32, 2, 2, EPI>(d, s);
             case 7: return launch_cfg<512, 128, 64, 8, 1, EPI>(d, s);
             default:
-                if (d.variant >= 8) return launch_cfg<256, 256, 64, 2, 4, EPI, true>(d, s);
+                if (d.variant >= 8) return launch_cfg<256, 256, 64, 2, 4, EPI, 1>(d, s);
                 return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
         }
     }

@@ -29,7 +29,7 @@ ACT_NONE, ACT_SIGMOID, ACT_RELU = 0, 1, 2
 EXPORTS = (
     "ada_abi_version", "ada_operand_dtype", "ada_last_error", "ada_igemm", "ada_attention_fwd",
     "ada_rowstats_finalize", "ada_layernorm_fwd", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
-    "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd",
+    "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd", "ada_dpt_tail_fwd",
     "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
     "ada_debug_set_timestamps", "ada_debug_set_attention_variant", "ada_debug_set_attention_profile",
 )
@@ -115,6 +115,9 @@ def load(path: Optional[str] = None):
     lib.ada_blend_fwd.restype = c_int
     lib.ada_tile_blend_fwd.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
     lib.ada_tile_blend_fwd.restype = c_int
+    lib.ada_dpt_tail_fwd.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                     c_float, c_int32, c_void_p, c_void_p]
+    lib.ada_dpt_tail_fwd.restype = c_int
     lib.ada_depth_eval_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_float, c_float, c_void_p, c_void_p]
     lib.ada_depth_eval_fwd.restype = c_int
     for name in ("ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_set_attention_variant"):
@@ -273,6 +276,17 @@ def bilinear(inp, ld_in, batch, hi, wi, ho, wo, channels, *, add=None, ld_add=0,
     _check(load().ada_bilinear_fwd(_dev(inp, "in", torch.float32), ld_in, batch, hi, wi, ho, wo, channels,
                                    _opt(add, "add", torch.float32), ld_add, _opt(out_f32, "out_f32", torch.float32), ld_f32,
                                    _opt(out_op, "out_op", op), ld_op, map_op, int(relu), split_seg, _stream()), "ada_bilinear_fwd")
+
+
+def dpt_tail(inp, ld_in, batch, hi, wi, ho, wo, cp, w, bias, tail_w, tail_b, tail_act, out):
+    """Fused bilinear resize + output_conv2 (3x3 -> ReLU -> 1x1 -> activation), ada_dpt_tail_fwd."""
+    op = operand_dtype()
+    ev = _timer.start() if _timer is not None else None
+    _check(load().ada_dpt_tail_fwd(_dev(inp, "in", torch.float32), ld_in, batch, hi, wi, ho, wo, cp, _dev(w, "w", op),
+                                   _dev(bias, "bias", torch.float32), _dev(tail_w, "tail_w", torch.float32), tail_b, tail_act,
+                                   _dev(out, "out", torch.float32), _stream()), "ada_dpt_tail_fwd")
+    if ev is not None:
+        _timer.stop("dpt_tail", ev, 2.0 * batch * ho * wo * 32 * 9 * cp)
 
 
 def minmax(inp, minmax_out):

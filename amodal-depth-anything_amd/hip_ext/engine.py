@@ -18,6 +18,7 @@ inputs carry a one-pixel zero border so the implicit-GEMM gather never branches.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -27,6 +28,7 @@ from . import (A_CONV3, A_PLAIN, ACT_NONE, ACT_RELU, ACT_SIGMOID, EP_BIAS, EP_GA
                EP_ROWSTATS, EP_SWIGLU, EP_TAIL, MAP_PAD, MAP_PLAIN, MAP_SHUFFLE, MAP_TOKEN, HipExtError)
 from . import attention as k_attention
 from . import bilinear as k_bilinear
+from . import dpt_tail as k_dpt_tail
 from . import igemm as k_igemm
 from . import layernorm as k_layernorm
 from . import operand_dtype
@@ -36,6 +38,11 @@ from . import write_cls as k_write_cls
 
 PATCH = 14
 LN_EPS = 1e-6
+# ada_dpt_tail_fwd (resize + output_conv2 fused, the up-sampled map never materialised) is built and parity-tested but OFF by default:
+# at ViT-L bs=32 it takes 2.69 ms against 2.18 ms for the resize kernel + tail GEMM it replaces -- with 123 KB of LDS only one 4-wave
+# workgroup fits a CU, so its interpolation phase runs at one wave per SIMD (1.18 ms) and 35 k short-lived workgroups pay their
+# dispatch one after the other (0.57 ms with every phase ablated).  profiles/r02_h_fused_tail_ablation.txt.  ADA_FUSED_TAIL=1 enables it.
+FUSED_TAIL = os.environ.get("ADA_FUSED_TAIL", "0") == "1"
 VIT = {
     "vits": dict(dim=384, depth=12, heads=6, ffn="mlp"),
     "vitb": dict(dim=768, depth=12, heads=12, ffn="mlp"),
@@ -284,7 +291,10 @@ class Workspace:
         half = Fch // 2
         self.half, self.halfp = half, _r64(half)
         self.oc1 = z(B * self.g296[0] * self.g296[1], half, dtype=torch.float32)
-        self.fin = z(B, H + 2, W + 2, m * self.halfp)
+        # fused tail (ada_dpt_tail_fwd): resize + output_conv2 in one kernel, the up-sampled map is never materialised.  Needs the
+        # single-precision head and a channel count that is already a multiple of 64 (ViT-B / ViT-L heads)
+        self.fused_tail = (not pw_.split_head) and half == self.halfp and FUSED_TAIL
+        self.fin = None if self.fused_tail else z(B, H + 2, W + 2, m * self.halfp)
 
 
 class DepthEngine:
@@ -463,8 +473,11 @@ class DepthEngine:
 
         # ---- output_conv1 -> resize to (14 ph, 14 pw) -> output_conv2 (3x3, ReLU, 1x1, activation) (dpt.py:193-195) ----
         self._conv3(ws.p1, w.oc1_w, B * g2[0] * g2[1], ws.half, g2, cin=Fch, bias=w.oc1_b, flags=EP_BIAS, out_f32=ws.oc1, ldo_f32=ws.half)
+        out = torch.empty(B, 1, ws.H, ws.W, dtype=torch.float32, device=ws.oc1.device)
+        if ws.fused_tail:
+            k_dpt_tail(ws.oc1, ws.half, B, g2[0], g2[1], ws.H, ws.W, ws.halfp, w.oc2_w, w.oc2_b, w.tail_w, w.tail_b, self.final_act, out)
+            return out
         k_bilinear(ws.oc1, ws.half, B, g2[0], g2[1], ws.H, ws.W, ws.half, out_op=ws.fin, ld_op=ws.fin.shape[3], map_op=MAP_PAD, split_seg=S(ws.halfp))
-        out = torch.empty(B, 1, ws.H, ws.W, dtype=torch.float32, device=ws.fin.device)
         self._conv3(ws.fin, w.oc2_w, B * ws.H * ws.W, w.oc2_w.shape[0], (ws.H, ws.W), cin=ws.half, bias=w.oc2_b, flags=EP_BIAS | EP_TAIL,
                     out_f32=out, ldo_f32=1, tail_w=w.tail_w, tail_b=w.tail_b, tail_act=self.final_act)
         return out

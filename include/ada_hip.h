@@ -207,6 +207,18 @@ int ada_bilinear_fwd(const float* in, int64_t ld_in, int32_t batch, int32_t hi, 
                      int32_t relu, int32_t split_seg, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused DPT tail: bilinear resize (align_corners=True) of the fp32 NHWC map `in` [B, hi, wi, >= cp channels] to [B, ho, wo],
+ * 3x3 convolution (padding 1) to 32 channels + bias, ReLU, 1x1 convolution to one channel + tail_b, activation -- reference
+ * DA2/dpt.py:194-195 (F.interpolate + scratch.output_conv2; raw model RAW/dpt.py:148-150) in one kernel; the up-sampled
+ * map is never written to memory.  w: op-typed [32, 9 * cp] tap-major (the ada_igemm CONV3 packing), cp = channels padded to
+ * a multiple of 64 (weights of pad channels zero; `in` rows must hold cp readable floats: ld_in >= cp).  out: fp32 [B, ho, wo].
+ * Up-sampling only (ho >= hi, wo >= wi in practice: the source patch of an 8 x 32 output block must fit in LDS).
+ * ---------------------------------------------------------------------------------------- */
+int ada_dpt_tail_fwd(const float* in, int64_t ld_in, int32_t batch, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                     int32_t cp, const void* w, const float* bias, const float* tail_w, float tail_b, int32_t tail_act,
+                     float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Depth evaluation sums.  Replaces the host-side numpy/torch evaluation of the reference:
  * the masked reductions behind src/util/metric.py:37-160 (abs_relative_difference, squared_relative_difference,
  * rmse_linear, rmse_log, log10, threshold_percentage = delta1/2/3, i_rmse, silog_rmse) and the normal-equation sums of

@@ -791,3 +791,34 @@ def test_igemm_layernorm_fold_pipeline(hip, forced_tile, cfg, gelu):
     print(f"cfg {cfg} gelu {gelu}: folded rel-L1 {e_fold:.2e} vs stand-alone LayerNorm path {e_unf:.2e}")
     assert e_fold < max(2.0 * e_unf, 1e-3 if op == torch.float16 else 8e-3)
     _close(out, ref, 6e-3, rtol=2e-2 if op == torch.bfloat16 else 6e-3, what="folded LN consumer")
+
+
+# =====================================================================================================================
+# Fused DPT tail: bilinear resize + 3x3 conv (-> 32) + ReLU + 1x1 (-> 1) + activation in one kernel (ada_dpt_tail_fwd)
+# =====================================================================================================================
+@pytest.mark.parametrize("B,C,hi,wi,ho,wo", [(2, 64, 9, 11, 16, 19), (1, 128, 20, 30, 35, 52), (2, 128, 17, 17, 30, 30), (1, 64, 40, 37, 70, 65),
+                                             (1, 128, 8, 40, 8, 70)])
+@pytest.mark.parametrize("act", ["sigmoid", "relu", "none"])
+def test_dpt_tail_fused(hip, B, C, hi, wi, ho, wo, act):
+    op = _op(hip)
+    x = _rand(B, C, hi, wi, seed=501)
+    w = (_rand(32, C, 3, 3, seed=502) * (9 * C) ** -0.5).to(op).float()
+    b = _rand(32, seed=503)
+    tw, tb = _rand(32, seed=504), 0.2
+    code = {"sigmoid": hip.ACT_SIGMOID, "relu": hip.ACT_RELU, "none": hip.ACT_NONE}[act]
+    xin = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV)
+    wp = _pack3(w, C, op).to(DEV)
+    out = torch.full((B, ho, wo), float("nan"), device=DEV)
+    hip.dpt_tail(xin, C, B, hi, wi, ho, wo, C, wp, b.to(DEV), tw.to(DEV), tb, code, out)
+    up = F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=True).to(op).float()
+    d = (F.relu(F.conv2d(up, w, b, padding=1)) * tw.view(1, -1, 1, 1)).sum(1) + tb
+    ref = {"sigmoid": torch.sigmoid, "relu": F.relu, "none": lambda t: t}[act](d)
+    _close(out, ref, 2e-3 if op == torch.bfloat16 else 4e-4, rtol=1e-2 if op == torch.bfloat16 else 1e-3, what=f"fused tail {act}")
+    # and against the two-launch path of the same library (resize kernel -> padded operand map -> tail GEMM)
+    fin = torch.zeros(B, ho + 2, wo + 2, C, dtype=op, device=DEV)
+    hip.bilinear(xin, C, B, hi, wi, ho, wo, C, out_op=fin, ld_op=C, map_op=hip.MAP_PAD)
+    out2 = torch.zeros(B, 1, ho, wo, device=DEV)
+    hip.igemm(M=B * ho * wo, N=32, K=9 * C, A=fin, lda=C, W=wp, a_mode=hip.A_CONV3, conv=(ho, wo, ho + 2, wo + 2, 1), bias=b.to(DEV),
+              flags=hip.EP_BIAS | hip.EP_TAIL, out_f32=out2, ldo_f32=1, tail_w=tw.to(DEV), tail_b=tb, tail_act=code)
+    # same arithmetic, but the interpolated operand is rounded from differently contracted fp32 expressions: a few fp16 ulps flip
+    _close(out, out2[:, 0], 6e-4, rtol=1e-3, what="fused tail vs two-launch path")

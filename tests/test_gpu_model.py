@@ -94,6 +94,25 @@ def test_hip_forward_matches_oracle_full_map_and_batch_invariance(hip):
     assert torch.equal(one[0], out[1]), "HIP path is not batch invariant"
 
 
+def test_fused_tail_on_and_off(hip, monkeypatch):
+    """ada_dpt_tail_fwd (resize + output_conv2 in one kernel; off by default) against the reference golden and the two-launch tail."""
+    from hip_ext import engine as E
+    gold, meta = load_golden("vitb_518")
+    case = meta["case"]
+    x, grgb, mask, obs = case_inputs(case)
+    st = case["stride"]
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(E, "FUSED_TAIL", fused)
+        model = build_product_model(case)
+        model.load_state_dict(synth_state_dict(model, meta), strict=True)
+        outs[fused] = _run_product(model, case, x, grgb, mask, obs)
+        err = rel_l1(outs[fused][..., ::st, ::st], gold)
+        print(f"vitb_518 fused_tail={fused}: rel-L1 = {err:.3e}")
+        assert err <= TOL
+    assert rel_l1(outs[True], outs[False]) < 2e-4
+
+
 def test_layernorm_folding_on_and_off(hip):
     """The block LayerNorms folded into qkv / fc1 (default) and as stand-alone launches: both meet the bar on ViT-B at batch 8, and the
     folded forward issues 2 * depth - 1 fewer LayerNorm launches."""

@@ -303,6 +303,52 @@ __global__ __launch_bounds__(256) void bilinear_tiled_kernel(BilinearArgs p, int
     }
 }
 
+// Bicubic resample of the learned position table to another patch grid (reference DA2/dinov2.py:199-230: F.interpolate(mode="bicubic",
+// antialias=False, scale_factor=...), i.e. ATen's upsample_bicubic2d with align_corners=False): cubic-convolution weights with A = -0.75,
+// source coordinate (dst + 0.5) * (1 / scale_factor) - 0.5 (not clamped), tap indices clamped to the grid.  One thread per (output
+// token, 4 channels); row 0 (cls position) is copied.  A parameter transform -- it runs once per grid size, not per image.
+ADA_DEV void cubic_coeffs(float t, float (&c)[4]) {
+    const float A = -0.75f;
+    const float x1 = t, x2 = 1.0f - t;
+    c[0] = ((A * (x1 + 1.0f) - 5.0f * A) * (x1 + 1.0f) + 8.0f * A) * (x1 + 1.0f) - 4.0f * A;
+    c[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+    c[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+    c[3] = ((A * (x2 + 1.0f) - 5.0f * A) * (x2 + 1.0f) + 8.0f * A) * (x2 + 1.0f) - 4.0f * A;
+}
+
+__global__ __launch_bounds__(256) void pos_embed_resize_kernel(const float* __restrict__ pos, int sq, int dim, int ph, int pw, float inv_sh,
+                                                               float inv_sw, float* __restrict__ out) {
+    const int c4 = dim >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)(1 + ph * pw) * c4) return;
+    const int tok = (int)(idx / c4), c = (int)(idx - (long)tok * c4);
+    if (tok == 0) {
+        ((float4*)out)[c] = ((const float4*)pos)[c];
+        return;
+    }
+    const int oy = (tok - 1) / pw, ox = (tok - 1) - oy * pw;
+    const float fy = ((float)oy + 0.5f) * inv_sh - 0.5f, fx = ((float)ox + 0.5f) * inv_sw - 0.5f;
+    const float fly = floorf(fy), flx = floorf(fx);
+    const int iy = (int)fly, ix = (int)flx;
+    float cy[4], cx[4];
+    cubic_coeffs(fy - fly, cy);
+    cubic_coeffs(fx - flx, cx);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+        const int yy = min(max(iy - 1 + ky, 0), sq - 1);
+        float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const int xx = min(max(ix - 1 + kx, 0), sq - 1);
+            const float4 v = ((const float4*)(pos + (long)(1 + yy * sq + xx) * dim))[c];
+            row.x += v.x * cx[kx]; row.y += v.y * cx[kx]; row.z += v.z * cx[kx]; row.w += v.w * cx[kx];
+        }
+        acc.x += row.x * cy[ky]; acc.y += row.y * cy[ky]; acc.z += row.z * cy[ky]; acc.w += row.w * cy[ky];
+    }
+    ((float4*)(out + (long)tok * dim))[c] = acc;
+}
+
 // (mean, rstd) per row from the per-group partial sums of an ADA_EP_ROWSTATS epilogue: one thread per row, fp32, fixed summation order
 __global__ __launch_bounds__(256) void rowstats_finalize_kernel(const float* __restrict__ partials, int rows, int groups, float eps, float* __restrict__ stats) {
     const int r = blockIdx.x * 256 + threadIdx.x;
@@ -321,6 +367,15 @@ __global__ __launch_bounds__(256) void rowstats_finalize_kernel(const float* __r
 }
 
 }  // namespace
+
+extern "C" int ada_pos_embed_resize(const float* pos, int32_t sq, int32_t dim, int32_t ph, int32_t pw, double scale_h, double scale_w, float* out,
+                                    void* stream) {
+    ADA_REQUIRE(pos && out && sq > 0 && ph > 0 && pw > 0 && dim > 0 && dim % 4 == 0 && scale_h > 0 && scale_w > 0, ADA_EINVAL, "ada_pos_embed_resize: bad arguments");
+    const long n = (long)(1 + ph * pw) * (dim / 4);
+    hipLaunchKernelGGL(pos_embed_resize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, sq, dim, ph, pw,
+                       (float)(1.0 / scale_h), (float)(1.0 / scale_w), out);
+    return ada_check_launch("ada_pos_embed_resize");
+}
 
 extern "C" int ada_rowstats_finalize(const float* partials, int32_t rows, int32_t groups, float eps, float* stats, void* stream) {
     ADA_REQUIRE(partials && stats && rows > 0 && groups > 0, ADA_EINVAL, "ada_rowstats_finalize: bad arguments");

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 from typing import Optional
 
 import torch
@@ -28,7 +28,7 @@ ACT_NONE, ACT_SIGMOID, ACT_RELU = 0, 1, 2
 
 EXPORTS = (
     "ada_abi_version", "ada_operand_dtype", "ada_last_error", "ada_igemm", "ada_attention_fwd",
-    "ada_rowstats_finalize", "ada_layernorm_fwd", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
+    "ada_rowstats_finalize", "ada_pos_embed_resize", "ada_layernorm_fwd", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
     "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd", "ada_dpt_tail_fwd",
     "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
     "ada_debug_set_timestamps", "ada_debug_set_attention_variant", "ada_debug_set_attention_profile",
@@ -90,6 +90,8 @@ def load(path: Optional[str] = None):
     lib.ada_last_error.restype = c_char_p
     lib.ada_igemm.argtypes = [ctypes.POINTER(IgemmArgs), c_void_p]
     lib.ada_igemm.restype = c_int
+    lib.ada_pos_embed_resize.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_int32, c_double, c_double, c_void_p, c_void_p]
+    lib.ada_pos_embed_resize.restype = c_int
     lib.ada_rowstats_finalize.argtypes = [c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p]
     lib.ada_rowstats_finalize.restype = c_int
     lib.ada_attention_fwd.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]
@@ -263,6 +265,12 @@ def patchify(x, guide, batch, cg, height, width, mean, inv_std, out, ld, split=F
         m = s = None
     _check(load().ada_patchify(_dev(x, "x", torch.float32), _opt(guide, "guide", torch.float32), batch, cg, height, width,
                                m, s, _dev(out, "out", op), ld, int(split), _stream()), "ada_patchify")
+
+
+def pos_embed_resize(pos, sq, dim, ph, pw, scale_h, scale_w, out):
+    """pos fp32 [1 + sq*sq, dim] -> out fp32 [1 + ph*pw, dim] (ada_pos_embed_resize: bicubic, ATen semantics)."""
+    _check(load().ada_pos_embed_resize(_dev(pos, "pos", torch.float32), sq, dim, ph, pw, float(scale_h), float(scale_w),
+                                       _dev(out, "out", torch.float32), _stream()), "ada_pos_embed_resize")
 
 
 def write_cls(tokens, batch, n_tokens, dim, cls, pos0):

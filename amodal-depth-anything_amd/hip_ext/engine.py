@@ -33,6 +33,7 @@ from . import igemm as k_igemm
 from . import layernorm as k_layernorm
 from . import operand_dtype
 from . import patchify as k_patchify
+from . import pos_embed_resize as k_pos_embed_resize
 from . import rowstats_finalize as k_rowstats_finalize
 from . import write_cls as k_write_cls
 
@@ -218,7 +219,7 @@ class PackedWeights:
     def pos_embed(self, ph: int, pw: int) -> torch.Tensor:
         """[1 + ph*pw, D] fp32 position table for a ph x pw patch grid (reference DA2/dinov2.py:199-230).
         The native 37x37 square grid is used as is; anything else is a one-off bicubic resample of the
-        parameter (cached per grid) -- a parameter transform like weight packing, not part of the per-image path."""
+        parameter by ada_pos_embed_resize (cached per grid) -- a parameter transform like weight packing, not part of the per-image path."""
         key = (ph, pw)
         if key in self._pos_cache:
             return self._pos_cache[key]
@@ -228,10 +229,10 @@ class PackedWeights:
             sq = int(math.sqrt(n))
             # reference quirk kept on purpose: w0 is derived from x.shape[2] (image *height*) -- dinov2.py:233,209
             w0, h0 = ph + 0.1, pw + 0.1
-            grid = pos[:, 1:].reshape(1, sq, sq, -1).permute(0, 3, 1, 2)
-            grid = F.interpolate(grid, scale_factor=(float(w0) / sq, float(h0) / sq), mode="bicubic", antialias=False)
-            assert grid.shape[-2] == ph and grid.shape[-1] == pw
-            pos = torch.cat([pos[:, :1], grid.permute(0, 2, 3, 1).reshape(1, ph * pw, -1)], dim=1)
+            src = pos[0].contiguous()
+            res = torch.empty(1 + ph * pw, src.shape[1], dtype=torch.float32, device=src.device)
+            k_pos_embed_resize(src, sq, src.shape[1], ph, pw, float(w0) / sq, float(h0) / sq, res)
+            pos = res[None]
         out = pos[0].contiguous()
         self._pos_cache[key] = out
         return out

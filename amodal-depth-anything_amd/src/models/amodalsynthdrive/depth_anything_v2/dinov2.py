@@ -86,11 +86,12 @@ class DinoVisionTransformer(nn.Module):
         pos = self.pos_embed.float()
         w0, h0 = w // self.patch_size + self.interpolate_offset, h // self.patch_size + self.interpolate_offset
         sq = math.sqrt(n)
-        grid = pos[:, 1:].reshape(1, int(sq), int(sq), -1).permute(0, 3, 1, 2)
-        grid = nn.functional.interpolate(grid, scale_factor=(float(w0) / sq, float(h0) / sq), mode="bicubic",
-                                         antialias=self.interpolate_antialias)
-        assert int(w0) == grid.shape[-2] and int(h0) == grid.shape[-1]
-        return torch.cat((pos[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, x.shape[-1])), dim=1).to(x.dtype)
+        if self.interpolate_antialias:
+            raise NotImplementedError("antialiased position-table resampling is not used by any shipped configuration")
+        import hip_ext
+        out = torch.empty(1 + int(w0) * int(h0), pos.shape[-1], dtype=torch.float32, device=pos.device)
+        hip_ext.pos_embed_resize(pos[0].contiguous(), int(sq), pos.shape[-1], int(w0), int(h0), float(w0) / sq, float(h0) / sq, out)
+        return out[None].to(x.dtype)
 
     def prepare_tokens_with_masks(self, x, masks=None, guidance_mask=None):
         if masks is not None:

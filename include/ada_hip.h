@@ -189,6 +189,13 @@ int ada_patchify(const float* x, const float* guide, int32_t batch, int32_t cg, 
                  int32_t width, const float* mean, const float* inv_std, void* out, int64_t ld,
                  int32_t split, void* stream);
 
+/* Position table for a patch grid other than the native sq x sq one (DA2/dinov2.py:199-230): bicubic resample (ATen
+ * upsample_bicubic2d semantics: A = -0.75, align_corners = False, the given scale factors, antialias off) of
+ * pos[1:, :] viewed as [sq, sq, dim]; row 0 (cls) is copied.  pos: fp32 [1 + sq*sq, dim]; out: fp32 [1 + ph*pw, dim];
+ * scale_h / scale_w: the scale_factor pair the reference passes ((ph + 0.1) / sq, (pw + 0.1) / sq).  Runs once per grid. */
+int ada_pos_embed_resize(const float* pos, int32_t sq, int32_t dim, int32_t ph, int32_t pw, double scale_h,
+                         double scale_w, float* out, void* stream);
+
 /* cls row of the token matrix: tokens[b, 0, :] = cls + pos[0]  (DA2/dinov2.py:245-246). */
 int ada_write_cls(float* tokens, int32_t batch, int32_t n_tokens, int32_t dim, const float* cls,
                   const float* pos0, void* stream);

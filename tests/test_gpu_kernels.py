@@ -822,3 +822,17 @@ def test_dpt_tail_fused(hip, B, C, hi, wi, ho, wo, act):
               flags=hip.EP_BIAS | hip.EP_TAIL, out_f32=out2, ldo_f32=1, tail_w=tw.to(DEV), tail_b=tb, tail_act=code)
     # same arithmetic, but the interpolated operand is rounded from differently contracted fp32 expressions: a few fp16 ulps flip
     _close(out, out2[:, 0], 6e-4, rtol=1e-3, what="fused tail vs two-launch path")
+
+
+@pytest.mark.parametrize("ph,pw,dim", [(19, 23, 384), (73, 73, 64), (16, 16, 128), (37, 50, 32), (9, 11, 1024)])
+def test_pos_embed_bicubic_resize_matches_aten(hip, ph, pw, dim):
+    """ada_pos_embed_resize against F.interpolate(mode='bicubic', scale_factor=((ph+0.1)/37, (pw+0.1)/37)) -- reference DA2/dinov2.py:219-225."""
+    sq = 37
+    pos = _rand(1 + sq * sq, dim, seed=601)
+    out = torch.full((1 + ph * pw, dim), float("nan"), device=DEV)
+    hip.pos_embed_resize(pos.to(DEV), sq, dim, ph, pw, (ph + 0.1) / sq, (pw + 0.1) / sq, out)
+    grid = pos[1:].reshape(1, sq, sq, dim).permute(0, 3, 1, 2)
+    ref = F.interpolate(grid, scale_factor=((ph + 0.1) / sq, (pw + 0.1) / sq), mode="bicubic", antialias=False)
+    assert ref.shape[-2:] == (ph, pw)
+    ref = torch.cat([pos[:1], ref.permute(0, 2, 3, 1).reshape(ph * pw, dim)], 0)
+    _close(out, ref, 3e-6, rtol=1e-5, what="bicubic pos embed")

@@ -188,6 +188,17 @@ class PackedWeights:
                 return triple(w).reshape(co, -1).contiguous()
 
         h = "depth_head."
+        # use_clstoken read-out (reference DA2/dpt.py:110-117,164-167): Linear(2D -> D) on [patch token | class token] + GELU.  The class
+        # token half is the same for every patch of an image, so it becomes a per-image bias  c_b = W_cls cls_b + b  (one tiny GEMM) and
+        # the patch half runs as a D -> D GEMM per image with that bias.
+        self.readout = f"{h}readout_projects.0.0.weight" in sd
+        if self.readout:
+            self.ro_wx, self.ro_wc, self.ro_b = [], [], []
+            for i in range(4):
+                wr = f32(f"{h}readout_projects.{i}.0.weight")
+                self.ro_wx.append(lin(wr[:, :D]))
+                self.ro_wc.append(lin(wr[:, D:]))
+                self.ro_b.append(f32(f"{h}readout_projects.{i}.0.bias"))
         self.oc = [sd[f"{h}projects.{i}.weight"].shape[0] for i in range(4)]
         self.features = sd[h + "scratch.layer1_rn.weight"].shape[0]
         self.proj_w = [lin(f32(f"{h}projects.{i}.weight")) for i in range(4)]
@@ -266,6 +277,10 @@ class Workspace:
         hidden = pw_.blocks[0]["hidden"]
         self.hd = z(T, hidden)
         self.taps = [z(P, m * D) for _ in range(4)]
+        if pw_.readout:
+            self.cls_op = [z(B, m * D) for _ in range(4)]                          # final-LayerNorm'd class tokens, operand-typed
+            self.cls_bias = [z(B, D, dtype=torch.float32) for _ in range(4)]       # W_cls cls + b per image
+            self.taps_ro = [z(P, m * D) for _ in range(4)]                         # read-out tokens (inputs of `projects`)
         # head grids
         self.grid = [(4 * ph, 4 * pw), (2 * ph, 2 * pw), (ph, pw), ((ph - 1) // 2 + 1, (pw - 1) // 2 + 1)]
         oc = pw_.oc
@@ -399,6 +414,10 @@ class DepthEngine:
                 tap = ws.taps[taps.index(i)]
                 k_layernorm(ws.x, D, P, D, w.norm_w, w.norm_b, LN_EPS, group_in=N, skip=1, out_op=tap, ld_op=tap.shape[1],
                             split_seg=D if w.split_head else 0)
+                if w.readout:   # the class token of every image (row b * N of the token matrix): input row stride N * D
+                    j = taps.index(i)
+                    k_layernorm(ws.x, N * D, B, D, w.norm_w, w.norm_b, LN_EPS, out_op=ws.cls_op[j], ld_op=ws.cls_op[j].shape[1],
+                                split_seg=D if w.split_head else 0)
 
         return self._head(ws, B)
 
@@ -418,17 +437,27 @@ class DepthEngine:
         def S(seg):   # split_seg argument of a producer whose consumer reads [hi | lo | hi] segments of width seg
             return seg if sp else 0
 
+        taps_in = ws.taps
+        if w.readout:   # x = GELU(W_x x + (W_cls cls_b + b))  per image (DA2/dpt.py:164-167)
+            KDr = ws.taps[0].shape[1]
+            Np = ph * pw
+            for i in range(4):
+                k_igemm(M=B, N=D, K=KDr, k_alg=D, A=ws.cls_op[i], lda=KDr, W=w.ro_wc[i], bias=w.ro_b[i], flags=EP_BIAS, out_f32=ws.cls_bias[i], ldo_f32=D)
+                for b in range(B):
+                    k_igemm(M=Np, N=D, K=KDr, k_alg=D, A=ws.taps[i][b * Np:(b + 1) * Np], lda=KDr, W=w.ro_wx[i], bias=ws.cls_bias[i][b],
+                            flags=EP_BIAS | EP_GELU, out_op=ws.taps_ro[i][b * Np:(b + 1) * Np], ldo_op=ws.taps_ro[i].shape[1], split_seg=S(D))
+            taps_in = ws.taps_ro
         # ---- reassemble: 1x1 project + resize (dpt.py:171-173) -> zero-bordered NHWC operand tensors -----
         KD = ws.taps[0].shape[1]
-        k_igemm(M=P, N=oc[0], K=KD, k_alg=D, A=ws.taps[0], lda=KD, W=w.proj_w[0], bias=w.proj_b[0], flags=EP_BIAS, out_op=ws.t0, ldo_op=ws.t0.shape[1], split_seg=S(ocp[0]))
+        k_igemm(M=P, N=oc[0], K=KD, k_alg=D, A=taps_in[0], lda=KD, W=w.proj_w[0], bias=w.proj_b[0], flags=EP_BIAS, out_op=ws.t0, ldo_op=ws.t0.shape[1], split_seg=S(ocp[0]))
         k_igemm(M=P, N=16 * oc[0], K=ws.t0.shape[1], k_alg=oc[0], A=ws.t0, lda=ws.t0.shape[1], W=w.rs0_w, bias=w.rs0_b, flags=EP_BIAS,
                 out_op=ws.L[0], ldo_op=ws.L[0].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=4, shuffle_c=oc[0], split_seg=S(ocp[0]))
-        k_igemm(M=P, N=oc[1], K=KD, k_alg=D, A=ws.taps[1], lda=KD, W=w.proj_w[1], bias=w.proj_b[1], flags=EP_BIAS, out_op=ws.t1, ldo_op=ws.t1.shape[1], split_seg=S(ocp[1]))
+        k_igemm(M=P, N=oc[1], K=KD, k_alg=D, A=taps_in[1], lda=KD, W=w.proj_w[1], bias=w.proj_b[1], flags=EP_BIAS, out_op=ws.t1, ldo_op=ws.t1.shape[1], split_seg=S(ocp[1]))
         k_igemm(M=P, N=4 * oc[1], K=ws.t1.shape[1], k_alg=oc[1], A=ws.t1, lda=ws.t1.shape[1], W=w.rs1_w, bias=w.rs1_b, flags=EP_BIAS,
                 out_op=ws.L[1], ldo_op=ws.L[1].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=2, shuffle_c=oc[1], split_seg=S(ocp[1]))
-        k_igemm(M=P, N=oc[2], K=KD, k_alg=D, A=ws.taps[2], lda=KD, W=w.proj_w[2], bias=w.proj_b[2], flags=EP_BIAS,
+        k_igemm(M=P, N=oc[2], K=KD, k_alg=D, A=taps_in[2], lda=KD, W=w.proj_w[2], bias=w.proj_b[2], flags=EP_BIAS,
                 out_op=ws.L[2], ldo_op=ws.L[2].shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S(ocp[2]))
-        k_igemm(M=P, N=oc[3], K=KD, k_alg=D, A=ws.taps[3], lda=KD, W=w.proj_w[3], bias=w.proj_b[3], flags=EP_BIAS,
+        k_igemm(M=P, N=oc[3], K=KD, k_alg=D, A=taps_in[3], lda=KD, W=w.proj_w[3], bias=w.proj_b[3], flags=EP_BIAS,
                 out_op=ws.pre3, ldo_op=ws.pre3.shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S(ocp[3]))
         self._conv3(ws.pre3, w.rs3_w, rows[3], oc[3], grid[3], stride=2, cin=oc[3], bias=w.rs3_b, flags=EP_BIAS,
                     out_op=ws.L[3], ldo_op=ws.L[3].shape[3], map_op=MAP_PAD, map_h=grid[3][0], map_w=grid[3][1], split_seg=S(ocp[3]))

@@ -42,11 +42,14 @@ class DPTHead(nn.Module):
     def __init__(self, in_channels, features=256, use_bn=False, out_channels=(256, 512, 1024, 1024), use_clstoken=False,
                  loss_stategy=None, with_input_projection=True):
         super().__init__()
-        if use_clstoken or use_bn:
-            raise NotImplementedError("use_clstoken / use_bn are off in every Depth-Anything-V2 configuration")
+        if use_bn:
+            raise NotImplementedError("use_bn is off in every Depth-Anything-V2 configuration (BatchNorm fusion blocks are not built)")
         oc = list(out_channels)
         self.use_clstoken = use_clstoken
         self.projects = nn.ModuleList([nn.Conv2d(in_channels, c, kernel_size=1) for c in oc])
+        if use_clstoken:   # read-out of the class token into every patch token (reference DA2/dpt.py:110-117, RAW/dpt.py:83-90)
+            self.readout_projects = nn.ModuleList(
+                [nn.Sequential(nn.Linear(2 * in_channels, in_channels), nn.GELU()) for _ in oc])
         self.resize_layers = nn.ModuleList([
             nn.ConvTranspose2d(oc[0], oc[0], kernel_size=4, stride=4, padding=0),
             nn.ConvTranspose2d(oc[1], oc[1], kernel_size=2, stride=2, padding=0),
@@ -78,6 +81,9 @@ class DPTHead(nn.Module):
         layers = []
         for i, feat in enumerate(out_features):
             x = feat[0]
+            if self.use_clstoken:   # DA2/dpt.py:164-167
+                lin = self.readout_projects[i][0]
+                x = HF.linear(torch.cat((x, feat[1].unsqueeze(1).expand_as(x)), -1), lin.weight, lin.bias, gelu=True)
             x = x.permute(0, 2, 1).reshape(x.shape[0], x.shape[-1], patch_h, patch_w)
             x = HF.conv2d(x, self.projects[i].weight, self.projects[i].bias)
             r = self.resize_layers[i]

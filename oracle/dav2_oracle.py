@@ -149,7 +149,7 @@ def block(nm, sd, p, x, heads, kind):
     return x + ffn(nm, sd, p + "mlp.", y, kind) * sd[p + "ls2.gamma"]
 
 
-def encoder_taps(nm, sd, pfx, encoder, x, guide, trace=None):
+def encoder_taps(nm, sd, pfx, encoder, x, guide, trace=None, return_class_token=False):
     """DA2/dinov2.py:298-308 + 324-349: taps taken *after* block i, shared final LN, cls dropped."""
     cfg = VIT[encoder]
     t = prepare_tokens(nm, sd, pfx, x, guide)
@@ -163,10 +163,13 @@ def encoder_taps(nm, sd, pfx, encoder, x, guide, trace=None):
             trace["block0"] = t
         if i in TAPS[encoder]:
             outs.append(t)
-    outs = [F.layer_norm(o, (D,), sd[pfx + "norm.weight"], sd[pfx + "norm.bias"], LN_EPS)[:, 1:] for o in outs]
+    normed = [F.layer_norm(o, (D,), sd[pfx + "norm.weight"], sd[pfx + "norm.bias"], LN_EPS) for o in outs]
+    outs = [o[:, 1:] for o in normed]
     if trace is not None:
         for j, o in enumerate(outs):
             trace[f"tap{j}"] = o
+    if return_class_token:     # DA2/dinov2.py:341-349: tuple(zip(patch tokens, class tokens))
+        return outs, [o[:, 0] for o in normed]
     return outs
 
 
@@ -201,11 +204,14 @@ def fusion_block(nm, sd, p, xs, size=None):
     return nm.conv(out, sd[p + "out_conv.weight"], sd[p + "out_conv.bias"])
 
 
-def dpt_head(nm, sd, pfx, taps, ph, pw, amodal, final_act, trace=None):
+def dpt_head(nm, sd, pfx, taps, ph, pw, amodal, final_act, trace=None, cls_tokens=None):
     """DA2/dpt.py:161-197 (amodal) / RAW/dpt.py:117-150 (raw: no input_projection)."""
     layers = []
     for i, x in enumerate(taps):
         B, _, D = x.shape
+        if cls_tokens is not None:   # use_clstoken read-out, DA2/dpt.py:164-167 (Linear(2D, D) + exact GELU, :110-117)
+            readout = cls_tokens[i].unsqueeze(1).expand_as(x)
+            x = F.gelu(nm.linear(torch.cat((x, readout), -1), sd[f"{pfx}readout_projects.{i}.0.weight"], sd[f"{pfx}readout_projects.{i}.0.bias"]))
         x = x.permute(0, 2, 1).reshape(B, D, ph, pw)
         x = nm.conv(x, sd[f"{pfx}projects.{i}.weight"], sd[f"{pfx}projects.{i}.bias"])
         if i == 0:
@@ -288,8 +294,12 @@ def raw_forward(sd: Dict[str, torch.Tensor], encoder: str, x, operand_dtype=torc
     """RAW DepthAnythingV2.forward, RAW/dpt.py:176-184: x is already normalised; returns [B,H,W]."""
     nm = _Numerics(operand_dtype)
     ph, pw = x.shape[-2] // PATCH, x.shape[-1] // PATCH
-    taps = encoder_taps(nm, sd, "pretrained.", encoder, x, None, trace)
-    depth = dpt_head(nm, sd, "depth_head.", taps, ph, pw, False, "relu", trace)  # head ReLU RAW/dpt.py:113
+    cls = None
+    if "depth_head.readout_projects.0.0.weight" in sd:   # use_clstoken=True (RAW/dpt.py:83-90,120-123)
+        taps, cls = encoder_taps(nm, sd, "pretrained.", encoder, x, None, trace, return_class_token=True)
+    else:
+        taps = encoder_taps(nm, sd, "pretrained.", encoder, x, None, trace)
+    depth = dpt_head(nm, sd, "depth_head.", taps, ph, pw, False, "relu", trace, cls_tokens=cls)  # head ReLU RAW/dpt.py:113
     return F.relu(depth).squeeze(1)  # RAW/dpt.py:182-184
 
 

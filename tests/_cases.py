@@ -28,12 +28,13 @@ def build_product_model(case):
         return get_model("AmodalDAv2", guide_type=case["guide_type"], loss_stategy=case["loss"], encoder=case["encoder"],
                          pretrained=False).eval()
     from src.models.amodalsynthdrive.depth_anything_v2_raw.dpt import DepthAnythingV2
-    return DepthAnythingV2(encoder=case["encoder"], features=case["features"], out_channels=case["out_channels"]).eval()
+    return DepthAnythingV2(encoder=case["encoder"], features=case["features"], out_channels=case["out_channels"],
+                           use_clstoken=case.get("use_clstoken", False)).eval()
 
 
 def schema_key(case):
     if case["kind"] == "raw":
-        return f"raw/{case['encoder']}"
+        return f"raw/{case['encoder']}" + ("/clstoken" if case.get("use_clstoken") else "")
     return f"amodal/{case['encoder']}/{case['guide_type']}"
 
 

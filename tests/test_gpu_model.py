@@ -218,6 +218,23 @@ def test_module_by_module_path_matches_oracle(hip):
     assert e1 <= TOL and e2 <= TOL
 
 
+def test_class_token_readout_modular_path(hip):
+    """use_clstoken=True through the module-by-module path (DPTHead.forward with readout_projects) against the oracle; the fused engine
+    path of the same model is covered by the raw_vits_clstoken reference golden."""
+    gold, meta = load_golden("raw_vits_clstoken")
+    case = meta["case"]
+    model = build_product_model(case)
+    sd = synth_state_dict(model, meta)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda()
+    x, grgb, mask, obs = case_inputs(case)
+    with torch.no_grad():
+        out = model.forward_modular(x.cuda()).cpu()
+    err = rel_l1(out, gold)
+    print(f"raw_vits_clstoken modular path: rel-L1 vs reference golden = {err:.3e}")
+    assert err <= TOL
+
+
 def test_raw_swiglu_module_path(hip):
     """ViT-G style SwiGLU block through the module-level functional path vs torch."""
     import torch.nn.functional as F

@@ -35,6 +35,12 @@ def test_raw_state_dict_matches_reference_schema(enc, feat, oc):
     assert _shapes(m) == SCHEMA[f"raw/{enc}"]
 
 
+def test_raw_state_dict_with_class_token_readout_matches_reference_schema():
+    with torch.device("meta"):
+        m = RawDepthAnythingV2(encoder="vits", features=64, out_channels=[48, 96, 192, 384], use_clstoken=True)
+    assert _shapes(m) == SCHEMA["raw/vits/clstoken"]
+
+
 def test_registry_and_error_behaviour():
     assert "AmodalDAv2" in model_name_class_dict
     with pytest.raises(NotImplementedError):

@@ -338,8 +338,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_v3(const op_t* __rest
 // =====================================================================================================================
 constexpr int PP_HALF_BYTES = 2 * K_TILE + 2 * V_TILE;   // 32 KB: [K0 | K1 | V0 | V1]
 
-// ABL (timing ablations only, results are garbage): 1 = no MFMAs, 2 = no softmax arithmetic, 3 = no fragment reads, 4 = no copies
-template <bool PRIO, bool PROF = false, int ABL = 0>
+template <bool PRIO, bool PROF = false>
 __global__ __launch_bounds__(512, 2) void attention_kernel_pp(const op_t* __restrict__ qkv, op_t* __restrict__ out,
                                                               int n_tok, int heads, int nqb, int n_bh, unsigned long long* prof = nullptr) {
     __shared__ __attribute__((aligned(16))) char smem[2 * PP_HALF_BYTES];
@@ -459,12 +458,10 @@ __global__ __launch_bounds__(512, 2) void attention_kernel_pp(const op_t* __rest
     auto m_interval = [&](auto parity, int j) {
         constexpr int P = decltype(parity)::value;     // j & 1
         const int tile = 2 * j + kh;
-        if (ABL != 4) {
         stage_k(P, tile + 4);                // K(j+2) -> K buffer j&1 (last read in the previous softmax interval)
         stage_v(P ^ 1, tile + 2);            // V(j+1) -> V buffer (j+1)&1
-        }
         __builtin_amdgcn_sched_barrier(0);
-        if (wave_active && ABL != 1) {
+        if (wave_active) {
             if (j > 0 && tile - 2 < nt) {    // O^T += V(j-1)^T P(j-1)^T
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -491,7 +488,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel_pp(const op_t* __rest
         }
         __builtin_amdgcn_sched_barrier(0);
         stamp(0);
-        if (ABL != 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the copies issued one interval ago (K(j+1), V(j)) have landed
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the copies issued one interval ago (K(j+1), V(j)) have landed
         stamp(1);
         __builtin_amdgcn_s_barrier();
         stamp(2);
@@ -502,7 +499,6 @@ __global__ __launch_bounds__(512, 2) void attention_kernel_pp(const op_t* __rest
         constexpr int P = decltype(parity)::value;
         const int tile = 2 * j + kh;
         // operands of the NEXT matrix interval: V(j) (transpose reads) and K(j+1); they land behind the softmax below
-        if (ABL != 3) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -517,8 +513,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel_pp(const op_t* __rest
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[kb][s]) : "v"(kofs[s]), "i"((P ^ 1) * K_TILE + kb * 32 * ROWB));
-        }
-        if (wave_active && tile < nt && ABL != 2) {
+        if (wave_active && tile < nt) {
             if (tile == nt - 1) {            // mask keys beyond the sequence (wave-uniform branch)
                 const int kv0 = tile * KVB;
 #pragma unroll

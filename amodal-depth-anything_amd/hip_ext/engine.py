@@ -219,8 +219,13 @@ class PackedWeights:
             d = dict(out_w=lin(f32(r + "out_conv.weight")), out_b=f32(r + "out_conv.bias"))
             for u in (1, 2):
                 for c in (1, 2):
-                    d[f"u{u}c{c}_w"] = conv3(f32(f"{r}resConfUnit{u}.conv{c}.weight"))
-                    d[f"u{u}c{c}_b"] = f32(f"{r}resConfUnit{u}.conv{c}.bias")
+                    w, b = f32(f"{r}resConfUnit{u}.conv{c}.weight"), f32(f"{r}resConfUnit{u}.conv{c}.bias")
+                    bn = f"{r}resConfUnit{u}.bn{c}."
+                    if bn + "running_var" in sd:      # use_bn=True: inference BatchNorm folded into the conv (reference blocks.py:70-76)
+                        from .functional import fold_batchnorm
+                        w, b = fold_batchnorm(w, b, f32(bn + "weight"), f32(bn + "bias"), f32(bn + "running_mean"), f32(bn + "running_var"))
+                    d[f"u{u}c{c}_w"] = conv3(w)
+                    d[f"u{u}c{c}_b"] = b.contiguous()
             self.fuse.append(d)  # index k-1
         self.oc1_w, self.oc1_b = conv3(f32(s + "output_conv1.weight")), f32(s + "output_conv1.bias")
         self.oc2_w, self.oc2_b = conv3(f32(s + "output_conv2.0.weight")), f32(s + "output_conv2.0.bias")
@@ -313,6 +318,41 @@ class Workspace:
         self.fin = None if self.fused_tail else z(B, H + 2, W + 2, m * self.halfp)
 
 
+GRAPH_MODE = os.environ.get("ADA_GRAPH", "auto")
+# "auto": graph replay for calls of up to one 518x518 image.  Measured (profiles/r02_k_hip_graph_latency_ab.txt): the forward is device-bound
+# from ViT-B upwards (replay == launches within 0.5 % at B = 1..8) and host-bound only for a single ViT-S image (3.55 -> 2.62 ms).
+GRAPH_AUTO_PIXELS = int(os.environ.get("ADA_GRAPH_AUTO_PIXELS", str(518 * 518)))
+
+
+class _GraphedForward:
+    """The launch sequence of DepthEngine._forward for one input shape, captured into a HIP graph.  The forward is a fixed list of
+    kernel launches over a pre-allocated workspace (no host synchronisation, no data-dependent control flow), so the capture is exact;
+    inputs are copied into the graph's static buffers and the result is cloned out of its pool."""
+
+    def __init__(self, eng: "DepthEngine", x: torch.Tensor, guide: Optional[torch.Tensor]):
+        dev = x.device
+        self.x = x.detach().contiguous().float().clone()
+        self.guide = None if guide is None else guide.detach().contiguous().float().clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):   # warm-up outside the capture: workspace, position table, per-kernel function attributes
+            eng._forward(self.x, self.guide)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = eng._forward(self.x, self.guide)
+
+    def __call__(self, x: torch.Tensor, guide: Optional[torch.Tensor]) -> torch.Tensor:
+        self.x.copy_(x)
+        if self.guide is not None:
+            if guide is None or guide.shape != self.guide.shape:
+                raise HipExtError(f"guide tensor of shape {tuple(self.guide.shape)} required")
+            self.guide.copy_(guide)
+        self.graph.replay()
+        return self.out.clone()
+
+
 class DepthEngine:
     """Runs one forward.  ``final_act``: 'sigmoid' | 'relu' | 'none'."""
 
@@ -321,6 +361,7 @@ class DepthEngine:
         self.final_act = {"sigmoid": ACT_SIGMOID, "relu": ACT_RELU, "none": ACT_NONE}[final_act]
         self.normalise_input = normalise_input
         self._ws: Dict[tuple, Workspace] = {}
+        self._graphs: Dict[tuple, "_GraphedForward"] = {}
 
     def max_batch(self, H: int, W: int) -> int:
         return max(1, MAX_ROWS // (H * W))
@@ -341,6 +382,21 @@ class DepthEngine:
                 conv=(grid[0], grid[1], Hp, Wp, stride), **kw)
 
     def forward(self, x: torch.Tensor, guide: Optional[torch.Tensor]) -> torch.Tensor:
+        """One forward.  The smallest problems are bound by the host's launch rate (~230 launches per image): for those the launch
+        sequence is captured once per input shape into a HIP graph and replayed, bit-identically (``ADA_GRAPH`` = auto | 1 | 0)."""
+        if not x.is_cuda:
+            raise HipExtError("DepthEngine.forward: input must live on a HIP device (no CPU fallback in the product path)")
+        mode = GRAPH_MODE
+        use = mode == "1" or (mode == "auto" and x.shape[0] * x.shape[-2] * x.shape[-1] <= GRAPH_AUTO_PIXELS)
+        if not use or torch.cuda.is_current_stream_capturing():
+            return self._forward(x, guide)
+        key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device))
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._graphs[key] = _GraphedForward(self, x, guide)
+        return g(x, guide)
+
+    def _forward(self, x: torch.Tensor, guide: Optional[torch.Tensor]) -> torch.Tensor:
         w = self.w
         if not x.is_cuda:
             raise HipExtError("DepthEngine.forward: input must live on a HIP device (no CPU fallback in the product path)")

@@ -211,6 +211,15 @@ def conv_transpose2d(x, weight, bias, stride):
     return out[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float().contiguous()
 
 
+def fold_batchnorm(w, b, bn_weight, bn_bias, running_mean, running_var, eps=1e-5):
+    """Inference BatchNorm2d behind a conv (reference blocks.py:70-76 with bn=True) as that conv's weight and bias:
+    bn(conv(x)) = conv(x) * s + (bn_bias - running_mean * s), s = bn_weight / sqrt(running_var + eps)  -- a parameter transform, done once."""
+    s = bn_weight.detach().float() / torch.sqrt(running_var.detach().float() + eps)
+    w2 = w.detach().float() * s.view(-1, 1, 1, 1)
+    b0 = b.detach().float() if b is not None else torch.zeros_like(s)
+    return w2, (b0 - running_mean.detach().float()) * s + bn_bias.detach().float()
+
+
 def residual_conv_unit(x, w1, b1, w2, b2):
     """ResidualConvUnit (reference blocks.py:57-80) with ReLU / residual fused into the conv epilogues."""
     _need_cuda(x, "residual_conv_unit input")

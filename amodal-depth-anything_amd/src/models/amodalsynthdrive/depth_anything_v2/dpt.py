@@ -42,8 +42,6 @@ class DPTHead(nn.Module):
     def __init__(self, in_channels, features=256, use_bn=False, out_channels=(256, 512, 1024, 1024), use_clstoken=False,
                  loss_stategy=None, with_input_projection=True):
         super().__init__()
-        if use_bn:
-            raise NotImplementedError("use_bn is off in every Depth-Anything-V2 configuration (BatchNorm fusion blocks are not built)")
         oc = list(out_channels)
         self.use_clstoken = use_clstoken
         self.projects = nn.ModuleList([nn.Conv2d(in_channels, c, kernel_size=1) for c in oc])

@@ -13,19 +13,33 @@ def _make_scratch(in_shape, out_shape, groups=1, expand=False):
 
 
 class ResidualConvUnit(nn.Module):
-    """conv2(relu(conv1(relu(x)))) + x -- the ReLU is not in place, so the skip adds the pre-activation x."""
+    """conv2(relu(conv1(relu(x)))) + x -- the ReLU is not in place, so the skip adds the pre-activation x.
+    bn=True (reference blocks.py:49-51,70-76; no shipped configuration) puts a BatchNorm2d behind each conv: inference uses the running
+    statistics, i.e. a per-channel affine map that is folded into the conv's weight and bias before they are packed."""
 
     def __init__(self, features, activation, bn):
         super().__init__()
-        if bn:
-            raise NotImplementedError("use_bn=True is not used by Depth-Anything-V2")
         self.bn, self.groups, self.activation = bn, 1, activation
         self.conv1 = nn.Conv2d(features, features, kernel_size=3, stride=1, padding=1, bias=True)
         self.conv2 = nn.Conv2d(features, features, kernel_size=3, stride=1, padding=1, bias=True)
+        if bn:
+            self.bn1 = nn.BatchNorm2d(features)
+            self.bn2 = nn.BatchNorm2d(features)
+
+    def folded(self):
+        """(w1, b1, w2, b2) with the BatchNorms (if any) folded in."""
+        from hip_ext.functional import fold_batchnorm
+        w1, b1, w2, b2 = self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias
+        if self.bn:
+            if self.training:
+                raise NotImplementedError("BatchNorm fusion blocks are inference-only here (running statistics); call .eval()")
+            w1, b1 = fold_batchnorm(w1, b1, self.bn1.weight, self.bn1.bias, self.bn1.running_mean, self.bn1.running_var, self.bn1.eps)
+            w2, b2 = fold_batchnorm(w2, b2, self.bn2.weight, self.bn2.bias, self.bn2.running_mean, self.bn2.running_var, self.bn2.eps)
+        return w1, b1, w2, b2
 
     def forward(self, x):
         from hip_ext import functional as HF
-        return HF.residual_conv_unit(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
+        return HF.residual_conv_unit(x, *self.folded())
 
 
 class FeatureFusionBlock(nn.Module):

@@ -49,7 +49,13 @@ def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int = 0) -> Dict[str, to
         def randn(*s):
             return torch.randn(*s, generator=g, dtype=torch.float32)
 
-        if _is_norm_key(key):
+        if leaf == "running_var":      # BatchNorm2d statistics (use_bn=True heads): strictly positive
+            v = 0.5 + torch.rand(*shape, generator=g, dtype=torch.float32)
+        elif leaf == "running_mean":
+            v = 0.2 * randn(*shape)
+        elif ".bn1." in key or ".bn2." in key:
+            v = 1.0 + 0.1 * randn(*shape) if leaf == "weight" else 0.1 * randn(*shape)
+        elif _is_norm_key(key):
             v = 1.0 + 0.1 * randn(*shape) if leaf == "weight" else 0.1 * randn(*shape)
         elif leaf == "gamma":  # LayerScale
             v = 0.3 + 0.7 * torch.rand(*shape, generator=g, dtype=torch.float32)

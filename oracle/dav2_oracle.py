@@ -185,9 +185,14 @@ def cf_layernorm(x, w, b):
 
 
 def residual_conv_unit(nm, sd, p, x):
-    """DA2/util/blocks.py:57-80 (bn=False; ReLU is *not* in place so +x is the pre-activation x)."""
-    out = nm.conv(F.relu(x), sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1)
-    out = nm.conv(F.relu(out), sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
+    """DA2/util/blocks.py:57-80 (ReLU is *not* in place so +x is the pre-activation x; bn=True adds an inference BatchNorm2d
+    behind each conv, :70-76 -- present iff the state_dict carries bn1/bn2)."""
+    def bn(t, q):
+        if q + "running_var" not in sd:
+            return t
+        return F.batch_norm(t, sd[q + "running_mean"], sd[q + "running_var"], sd[q + "weight"], sd[q + "bias"], False, 0.0, 1e-5)
+    out = bn(nm.conv(F.relu(x), sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1), p + "bn1.")
+    out = bn(nm.conv(F.relu(out), sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1), p + "bn2.")
     return out + x
 
 

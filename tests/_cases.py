@@ -29,19 +29,19 @@ def build_product_model(case):
                          pretrained=False).eval()
     from src.models.amodalsynthdrive.depth_anything_v2_raw.dpt import DepthAnythingV2
     return DepthAnythingV2(encoder=case["encoder"], features=case["features"], out_channels=case["out_channels"],
-                           use_clstoken=case.get("use_clstoken", False)).eval()
+                           use_clstoken=case.get("use_clstoken", False), use_bn=case.get("use_bn", False)).eval()
 
 
 def schema_key(case):
     if case["kind"] == "raw":
-        return f"raw/{case['encoder']}" + ("/clstoken" if case.get("use_clstoken") else "")
+        return f"raw/{case['encoder']}" + ("/clstoken" if case.get("use_clstoken") else "") + ("/bn" if case.get("use_bn") else "")
     return f"amodal/{case['encoder']}/{case['guide_type']}"
 
 
 def schema_state_dict(case, meta=None, seed=0):
     """Synthetic state_dict built from the reference's key/shape schema fixture (no nn.Module construction: fast)."""
     schema = json.load(open(os.path.join(GOLDEN_DIR, "state_dict_schema.json")))[schema_key(case)]
-    sd = {k: torch.zeros(shape) for k, shape in schema.items()}
+    sd = {k: torch.zeros(shape, dtype=torch.long if k.endswith("num_batches_tracked") else torch.float32) for k, shape in schema.items()}
     fill_state_dict_(sd, seed)
     if meta is not None:
         sd[meta["final_bias_key"]] = torch.full_like(sd[meta["final_bias_key"]], meta["final_bias"])

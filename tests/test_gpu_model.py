@@ -235,6 +235,23 @@ def test_class_token_readout_modular_path(hip):
     assert err <= TOL
 
 
+def test_batchnorm_fusion_blocks_modular_path(hip):
+    """use_bn=True through the module-by-module path (ResidualConvUnit.folded) against the reference golden; the fused engine path of the
+    same model is covered by the raw_vits_bn golden in test_model_matches_reference_golden."""
+    gold, meta = load_golden("raw_vits_bn")
+    case = meta["case"]
+    model = build_product_model(case)
+    sd = synth_state_dict(model, meta)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    x, grgb, mask, obs = case_inputs(case)
+    with torch.no_grad():
+        out = model.forward_modular(x.cuda()).cpu()
+    err = rel_l1(out, gold)
+    print(f"raw_vits_bn modular path: rel-L1 vs reference golden = {err:.3e}")
+    assert err <= TOL
+
+
 def test_raw_swiglu_module_path(hip):
     """ViT-G style SwiGLU block through the module-level functional path vs torch."""
     import torch.nn.functional as F

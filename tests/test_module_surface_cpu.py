@@ -41,6 +41,25 @@ def test_raw_state_dict_with_class_token_readout_matches_reference_schema():
     assert _shapes(m) == SCHEMA["raw/vits/clstoken"]
 
 
+def test_raw_state_dict_with_batchnorm_fusion_blocks_matches_reference_schema():
+    m = RawDepthAnythingV2(encoder="vits", features=64, out_channels=[48, 96, 192, 384], use_bn=True)
+    assert _shapes(m) == SCHEMA["raw/vits/bn"]
+    assert list(m.state_dict().keys()) == list(SCHEMA["raw/vits/bn"].keys())
+    rcu = m.depth_head.scratch.refinenet2.resConfUnit1
+    with pytest.raises(NotImplementedError):      # batch statistics (training mode) are not built
+        rcu.train().folded()
+    # the folded conv equals conv + inference BatchNorm
+    torch.manual_seed(0)
+    rcu.eval()
+    for bn in (rcu.bn1, rcu.bn2):
+        bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 1.5); bn.weight.data.normal_(1, 0.1); bn.bias.data.normal_(0, 0.1)
+    x = torch.randn(2, 64, 9, 11)
+    w1, b1, w2, b2 = rcu.folded()
+    want = rcu.bn1(rcu.conv1(x))
+    got = torch.nn.functional.conv2d(x, w1, b1, padding=1)
+    assert float((want - got).abs().max()) < 1e-5
+
+
 def test_registry_and_error_behaviour():
     assert "AmodalDAv2" in model_name_class_dict
     with pytest.raises(NotImplementedError):

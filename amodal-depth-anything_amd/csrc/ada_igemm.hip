@@ -71,15 +71,26 @@ struct IgemmDev {
     unsigned long long* dbg;  // optional per-block timestamps (ada_debug_set_timestamps)
 };
 
-// exact-erf GELU (nn.GELU default, reference mlp.py:23).  erf through the Abramowitz-Stegun 7.1.26 rational form
-// (|abs err| <= 1.5e-7, i.e. fp32-roundoff class) -- a third of the instructions of the libm erff in the hot epilogue.
+// exact-erf GELU (nn.GELU default, reference mlp.py:23): gelu(x) = x * Phi(x) = max(x, 0) - |x| * Phi(-|x|), with the lower tail
+// Phi(-a) = exp2(-q(a)), q = -log2(Phi(-a)) a smooth, nearly quadratic function fitted by a degree-6 polynomial on a in [0, 6]
+// (weighted for the error of the product; tools/fit_gelu.py).  fp32 evaluation: |error| <= 2.5e-7 over all x -- the class of the
+// Abramowitz-Stegun 7.1.26 form used before -- in 8 full-rate VALU operations + one exp2 instead of 15 + rcp + exp.
+// a is clamped to 12 (Phi(-12) ~ 2^-98 flushes the product to 0): the fitted q turns over far outside its interval.
 ADA_DEV float gelu_erf(float x) {
-    const float z = __builtin_fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = 1.0f - poly * __expf(-z * z);  // erf(|x|/sqrt2)
-    return 0.5f * x * (1.0f + __builtin_copysignf(e, x));
+    const float a = __builtin_fminf(__builtin_fabsf(x), 12.0f);
+    float q = -3.2904290173e-05f;
+    q = __builtin_fmaf(q, a, 7.6214928455e-04f);
+    q = __builtin_fmaf(q, a, -8.0387993652e-03f);
+    q = __builtin_fmaf(q, a, 5.3315321524e-02f);
+    q = __builtin_fmaf(q, a, 4.5887145819e-01f);
+    q = __builtin_fmaf(q, a, 1.1511568259e+00f);
+    q = __builtin_fmaf(q, a, 9.9999958888e-01f);
+    const float tail = __builtin_amdgcn_exp2f(-q);   // Phi(-|x|)
+    return __builtin_fmaf(-a, tail, __builtin_fmaxf(x, 0.0f));
 }
+
+// SiLU of the SwiGLU gate (reference swiglu_ffn.py:31): t * sigmoid(t), the division as one v_rcp (1 ulp) instead of the IEEE sequence
+ADA_DEV float silu(float t) { return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * t)); }
 
 // GEMM row -> row of an output buffer
 ADA_DEV long map_row(const IgemmDev& p, int map, uint32_t m) {
@@ -628,10 +639,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                     if (m < p.M && nval) {
                         float4 gt;
                         float t;
-                        t = x1.x + b1.x; gt.x = t / (1.0f + __expf(-t)) * (x2.x + b2.x);
-                        t = x1.y + b1.y; gt.y = t / (1.0f + __expf(-t)) * (x2.y + b2.y);
-                        t = x1.z + b1.z; gt.z = t / (1.0f + __expf(-t)) * (x2.z + b2.z);
-                        t = x1.w + b1.w; gt.w = t / (1.0f + __expf(-t)) * (x2.w + b2.w);
+                        gt.x = silu(x1.x + b1.x) * (x2.x + b2.x);
+                        gt.y = silu(x1.y + b1.y) * (x2.y + b2.y);
+                        gt.z = silu(x1.z + b1.z) * (x2.z + b2.z);
+                        gt.w = silu(x1.w + b1.w) * (x2.w + b2.w);
                         *(opx4*)(p.out_op + (long)m * p.ldo_op + nh) = pack4(gt);
                     }
                 }

@@ -364,6 +364,9 @@ class DepthEngine:
         self._graphs: Dict[tuple, "_GraphedForward"] = {}
 
     def max_batch(self, H: int, W: int) -> int:
+        if H * W > MAX_ROWS:
+            raise HipExtError(f"a {H}x{W} image has more than 2^24 pixels, the row limit of one kernel launch: "
+                              "use hip_ext.tiling.tiled_amodal_forward / tiled_raw_forward")
         return max(1, MAX_ROWS // (H * W))
 
     def workspace(self, B, H, W, device) -> Workspace:

@@ -30,6 +30,14 @@ def test_tile_origins_reject_small_images_and_bad_overlap():
         tiled_apply(lambda x: x, [torch.zeros(1, 3, 600, 600)])
 
 
+def test_engine_rejects_images_beyond_the_row_limit_with_a_pointer_to_tiling():
+    from hip_ext.engine import DepthEngine
+    eng = DepthEngine.__new__(DepthEngine)
+    assert eng.max_batch(518, 518) == 62 and eng.max_batch(4096, 4088) == 1
+    with pytest.raises(HipExtError, match="tiled"):
+        eng.max_batch(4102, 4102)
+
+
 def test_host_blend_is_a_partition_of_unity_and_cross_fades_linearly():
     th, tw, H, W, ov = 20, 30, 33, 50, 10
     origins = [(y, x) for y in TO.tile_origins(H, th, ov) for x in TO.tile_origins(W, tw, ov)]

@@ -638,7 +638,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                     const float4 x2 = *(const float4*)(slab + row * SW + 32 + 4 * c8);
                     if (m < p.M && nval) {
                         float4 gt;
-                        float t;
                         gt.x = silu(x1.x + b1.x) * (x2.x + b2.x);
                         gt.y = silu(x1.y + b1.y) * (x2.y + b2.y);
                         gt.z = silu(x1.z + b1.z) * (x2.z + b2.z);

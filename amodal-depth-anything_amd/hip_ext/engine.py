@@ -19,13 +19,13 @@ from __future__ import annotations
 
 import math
 import os
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 import torch.nn.functional as F
 
-from . import (A_CONV3, A_PLAIN, ACT_NONE, ACT_RELU, ACT_SIGMOID, EP_BIAS, EP_GAMMA, EP_GELU, EP_LNFOLD, EP_RELU_OP, EP_RESIDUAL,
-               EP_ROWSTATS, EP_SWIGLU, EP_TAIL, MAP_PAD, MAP_PLAIN, MAP_SHUFFLE, MAP_TOKEN, HipExtError)
+from . import (A_CONV3, ACT_NONE, ACT_RELU, ACT_SIGMOID, EP_BIAS, EP_GAMMA, EP_GELU, EP_LNFOLD, EP_RELU_OP, EP_RESIDUAL,
+               EP_ROWSTATS, EP_SWIGLU, EP_TAIL, MAP_PAD, MAP_SHUFFLE, MAP_TOKEN, HipExtError)
 from . import attention as k_attention
 from . import bilinear as k_bilinear
 from . import dpt_tail as k_dpt_tail

@@ -10,10 +10,9 @@ cast) only; every contraction, normalisation, softmax and resample runs in a HIP
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
 from . import (A_CONV3, ACT_NONE, ACT_RELU, ACT_SIGMOID, EP_BIAS, EP_GELU, EP_RELU_OP, EP_RESIDUAL, EP_SWIGLU, EP_TAIL,
-               MAP_PAD, MAP_PLAIN, MAP_SHUFFLE, HipExtError)
+               MAP_PAD, MAP_SHUFFLE, HipExtError)
 from . import attention as k_attention
 from . import bilinear as k_bilinear
 from . import igemm as k_igemm

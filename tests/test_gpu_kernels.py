@@ -1,6 +1,5 @@
 """GPU parity tests of each libada_hip entry point against a plain PyTorch fp32 computation of the same
 op on the same operand-rounded inputs (so the only differences are fp32 summation order)."""
-import math
 
 import pytest
 import torch

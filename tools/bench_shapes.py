@@ -15,6 +15,8 @@ import torch  # noqa: E402
 import hip_ext  # noqa: E402
 from hip_ext import engine as E  # noqa: E402
 
+E.GRAPH_MODE = "0"   # the launches are recorded through the Python wrappers: no graph replay here
+
 
 def main():
     ap = argparse.ArgumentParser()

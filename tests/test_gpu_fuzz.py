@@ -1,0 +1,115 @@
+"""GPU: seeded random-shape sweep of ada_igemm (plain linear layers) and ada_attention_fwd against fp32 torch on the same operand-rounded
+inputs.  Shapes are drawn so that every edge the kernels have is hit many times: single rows, ragged last tiles in M and N, N not a multiple of
+the tile width, lda / ldo larger than the logical width, odd numbers of k-tiles, forced and heuristic tile choices, every epilogue of the
+linear-layer path.  Output buffers carry guard columns / rows that must come back untouched (no out-of-bounds store)."""
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GUARD = 1024.0      # exactly representable in fp16 and bf16
+LOG2E = 1.4426950408889634
+
+
+def _mk(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        M = rng.choice([1, 2, 31, 64, 127, 128, 129, 255, 256, 257, 300, 511, 513, 777, 1370, 2740])
+        N = 8 * rng.choice([1, 2, 3, 4, 7, 8, 9, 16, 24, 31, 32, 33, 48, 64, 65, 96, 128, 130])
+        K = 64 * rng.choice([1, 2, 3, 4, 5, 8, 16, 17])
+        epi = rng.choice(["f32", "f32_res_gamma", "op", "op_gelu", "op_relu_and_f32", "op_gamma"])
+        tile = rng.choice([-1, -1, 0, 1, 2, 3, 4])
+        pad_a = 64 * rng.choice([0, 0, 1])
+        pad_o = 8 * rng.choice([0, 0, 1, 3])
+        out.append((i, M, N, K, epi, tile, pad_a, pad_o))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases(72, 20261002), ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}x{c[3]}-{c[4]}-t{c[5]}")
+def test_igemm_random_shapes(hip, case):
+    i, M, N, K, epi, tile, pad_a, pad_o = case
+    op = hip.operand_dtype()
+    lda, ldo = K + pad_a, N + pad_o
+    A_full = _mk((M, lda), 7 * i + 1).to(op).to(DEV)
+    A_full[:, K:] = float("nan")                                    # columns beyond K must never be read into the product
+    W = _mk((N, K), 7 * i + 2, K ** -0.5).to(op).to(DEV)
+    b = _mk((N,), 7 * i + 3).to(DEV)
+    g = (_mk((N,), 7 * i + 4) * 0.5 + 1).to(DEV)
+    lin = A_full[:, :K].float().cpu() @ W.float().cpu().T + b.cpu()
+    of = torch.full((M + 1, ldo), GUARD, device=DEV)
+    oo = torch.full((M + 1, ldo), GUARD, dtype=op, device=DEV)
+    tol_op = dict(atol=2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3)
+
+    def check(got, ref, atol, rtol=2e-3):
+        got = got.float().cpu()
+        body, ref = got[:M, :N], ref.float()
+        lim = atol + rtol * ref.abs()
+        bad = (body - ref).abs() > lim
+        assert not bad.any(), f"{int(bad.sum())}/{bad.numel()} off, max err {float((body - ref).abs().max()):.3e}"
+        assert bool((got[M] == GUARD).all()) and (pad_o == 0 or bool((got[:M, N:] == GUARD).all())), "store outside the M x N output"
+
+    hip.debug_set_tile(tile)
+    try:
+        if epi == "f32":
+            hip.igemm(M=M, N=N, K=K, A=A_full, lda=lda, W=W, bias=b, flags=hip.EP_BIAS, out_f32=of, ldo_f32=ldo)
+            check(of, lin, 3e-4)
+        elif epi == "f32_res_gamma":
+            x = _mk((M, N), 7 * i + 5).to(DEV)
+            of[:M, :N] = x
+            hip.igemm(M=M, N=N, K=K, A=A_full, lda=lda, W=W, bias=b, gamma=g, res=of, ldr=ldo, flags=hip.EP_BIAS | hip.EP_GAMMA | hip.EP_RESIDUAL,
+                      out_f32=of, ldo_f32=ldo)
+            check(of, x.cpu() + lin * g.cpu(), 3e-4)
+        elif epi == "op":
+            hip.igemm(M=M, N=N, K=K, A=A_full, lda=lda, W=W, bias=b, flags=hip.EP_BIAS, out_op=oo, ldo_op=ldo)
+            check(oo, lin, **tol_op)
+        elif epi == "op_gelu":
+            hip.igemm(M=M, N=N, K=K, A=A_full, lda=lda, W=W, bias=b, flags=hip.EP_BIAS | hip.EP_GELU, out_op=oo, ldo_op=ldo)
+            check(oo, F.gelu(lin), **tol_op)
+        elif epi == "op_relu_and_f32":
+            hip.igemm(M=M, N=N, K=K, A=A_full, lda=lda, W=W, bias=b, flags=hip.EP_BIAS | hip.EP_RELU_OP, out_f32=of, ldo_f32=ldo, out_op=oo, ldo_op=ldo)
+            check(of, lin, 3e-4)
+            check(oo, lin.clamp_min(0), **tol_op)
+        else:
+            hip.igemm(M=M, N=N, K=K, A=A_full, lda=lda, W=W, bias=b, gamma=g, flags=hip.EP_BIAS | hip.EP_GAMMA, out_op=oo, ldo_op=ldo)
+            check(oo, lin * g.cpu(), **tol_op)
+    finally:
+        hip.debug_set_tile(-1)
+
+
+def _attn_cases(n, seed):
+    rng = random.Random(seed)
+    return [(i, rng.choice([1, 2, 3]), rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 200, 257, 500, 1370]), rng.choice([1, 2, 6, 16]),
+             rng.choice([5, 3, 0])) for i in range(n)]
+
+
+@pytest.mark.parametrize("case", _attn_cases(36, 77), ids=lambda c: f"{c[0]}-B{c[1]}-N{c[2]}-h{c[3]}-v{c[4]}")
+def test_attention_random_shapes(hip, case):
+    i, B, N, heads, variant = case
+    op = hip.operand_dtype()
+    D = heads * 64
+    qkv = _mk((B * N + 1, 3 * D), 11 * i + 1)
+    qkv[:, :D] *= 0.125 * LOG2E          # the packer folds head_dim**-0.5 * log2(e) into q (base-2 softmax in the kernel)
+    qkv = qkv.to(op).to(DEV)
+    qkv[B * N] = float("nan")            # the row behind the last token must not leak into any softmax
+    out = torch.full((B * N + 1, D), GUARD, dtype=op, device=DEV)
+    hip.debug_set_attention_variant(variant)
+    try:
+        hip.attention(qkv, out, B, N, heads)
+    finally:
+        hip.debug_set_attention_variant(5)
+    t = qkv[:B * N].float().cpu().reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = (((t[0] @ t[1].transpose(-2, -1)) / LOG2E).softmax(-1) @ t[2]).transpose(1, 2).reshape(B * N, D)
+    got = out.float().cpu()
+    err = (got[:B * N] - ref).abs()
+    lim = (2e-2 if op == torch.bfloat16 else 4e-3) + 4e-3 * ref.abs()
+    assert not (err > lim).any(), f"max err {float(err.max()):.3e}"
+    assert bool((got[B * N] == GUARD).all()), "store behind the last token"

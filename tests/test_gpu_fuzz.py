@@ -113,3 +113,65 @@ def test_attention_random_shapes(hip, case):
     lim = (2e-2 if op == torch.bfloat16 else 4e-3) + 4e-3 * ref.abs()
     assert not (err > lim).any(), f"max err {float(err.max()):.3e}"
     assert bool((got[B * N] == GUARD).all()), "store behind the last token"
+
+
+# ---- the DPT head's operator set through the module-level wrappers (hip_ext.functional), random geometry ---------------------------------
+def _head_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        kind = rng.choice(["conv3", "conv3s2", "conv1", "convT2", "convT4", "rcu", "bilinear", "tail", "layer_norm"])
+        B = rng.choice([1, 2, 3])
+        H, W = rng.choice([1, 2, 3, 5, 8, 17, 37, 40]), rng.choice([1, 2, 4, 7, 16, 19, 37, 53])
+        C = rng.choice([4, 8, 48, 64, 96, 128, 192, 256])
+        Co = rng.choice([8, 32, 64, 96, 256])
+        out.append((i, kind, B, H, W, C, Co, rng.choice([(1, 1), (2, 3), (9, 5), (37, 37), (20, 41)])))
+    return out
+
+
+@pytest.mark.parametrize("case", _head_cases(63, 4242), ids=lambda c: f"{c[0]}-{c[1]}-B{c[2]}-{c[3]}x{c[4]}-C{c[5]}-Co{c[6]}")
+def test_head_operators_random_geometry(hip, case):
+    from hip_ext import functional as HF
+    i, kind, B, H, W, C, Co, size = case
+    op = hip.operand_dtype()
+
+    def rnd(shape, k, scale=1.0):
+        return _mk(shape, 13 * i + k, scale).to(op).float()        # operand-representable values: the only difference left is summation order
+
+    x = rnd((B, C, H, W), 1).to(DEV)
+    tol = dict(atol=3e-3 if op == torch.float16 else 3e-2, rtol=3e-3 if op == torch.float16 else 2e-2)
+
+    def close(got, ref):
+        err = (got.float().cpu() - ref).abs()
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        assert not (err > tol["atol"] + tol["rtol"] * ref.abs()).any(), f"max err {float(err.max()):.3e} (ref max {float(ref.abs().max()):.3e})"
+
+    if kind in ("conv3", "conv3s2"):
+        s = 2 if kind == "conv3s2" else 1
+        w, b = rnd((Co, C, 3, 3), 2, (9 * C) ** -0.5), rnd((Co,), 3)
+        close(HF.conv2d(x, w.to(DEV), b.to(DEV), stride=s, padding=1), F.conv2d(x.cpu(), w, b, stride=s, padding=1))
+    elif kind == "conv1":
+        w, b = rnd((Co, C, 1, 1), 2, C ** -0.5), rnd((Co,), 3)
+        close(HF.conv2d(x, w.to(DEV), b.to(DEV)), F.conv2d(x.cpu(), w, b))
+    elif kind in ("convT2", "convT4"):
+        s = 2 if kind == "convT2" else 4
+        w, b = rnd((C, Co, s, s), 2, C ** -0.5), rnd((Co,), 3)
+        ref = F.conv_transpose2d(x.cpu(), w, b, stride=s).to(op).float()       # the kernel writes operand-typed pixels
+        close(HF.conv_transpose2d(x, w.to(DEV), b.to(DEV), s), ref)
+    elif kind == "rcu":
+        w1, b1, w2, b2 = rnd((C, C, 3, 3), 2, (9 * C) ** -0.5), rnd((C,), 3), rnd((C, C, 3, 3), 4, (9 * C) ** -0.5), rnd((C,), 5)
+        mid = F.conv2d(torch.relu(x.cpu()), w1, b1, padding=1).relu().to(op).float()   # the intermediate is stored operand-typed
+        ref = F.conv2d(mid, w2, b2, padding=1) + x.cpu()
+        close(HF.residual_conv_unit(x, w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV)), ref)
+    elif kind == "bilinear":
+        close(HF.interpolate_bilinear_ac(x, size), F.interpolate(x.cpu(), size=size, mode="bilinear", align_corners=True))
+    elif kind == "tail":
+        w0, b0, w2, b2 = rnd((32, C, 3, 3), 2, (9 * C) ** -0.5), rnd((32,), 3), rnd((1, 32, 1, 1), 4, 0.3), rnd((1,), 5)
+        act = ["sigmoid", "relu", "none"][i % 3]
+        ref = F.conv2d(F.conv2d(x.cpu(), w0, b0, padding=1).relu(), w2, b2)
+        ref = torch.sigmoid(ref) if act == "sigmoid" else ref.relu() if act == "relu" else ref
+        close(HF.conv_tail(x, w0.to(DEV), b0.to(DEV), w2.to(DEV), b2.to(DEV), act), ref)
+    else:
+        t = _mk((B * H * W + 1, C * 4), 13 * i + 6, 2.0).to(DEV)
+        g, b = _mk((C * 4,), 13 * i + 7), _mk((C * 4,), 13 * i + 8)
+        close(HF.layer_norm(t, g.to(DEV), b.to(DEV), 1e-6), F.layer_norm(t.cpu(), (C * 4,), g, b, 1e-6))

@@ -175,3 +175,47 @@ def test_head_operators_random_geometry(hip, case):
         t = _mk((B * H * W + 1, C * 4), 13 * i + 6, 2.0).to(DEV)
         g, b = _mk((C * 4,), 13 * i + 7), _mk((C * 4,), 13 * i + 8)
         close(HF.layer_norm(t, g.to(DEV), b.to(DEV), 1e-6), F.layer_norm(t.cpu(), (C * 4,), g, b, 1e-6))
+
+
+# ---- whole model at random input sizes against the oracle run on the box (ViT-S: seconds on the host) --------------------------------------
+def _model_cases(n, seed):
+    rng = random.Random(seed)
+    guides = ["mask+observation", "image+mask+observation", "image+mask", "image+observation", "observation", "mask", "none"]
+    out = []
+    for i in range(n):
+        kind = "raw" if i % 4 == 3 else "amodal"
+        out.append((i, kind, rng.choice([1, 2, 3]), 14 * rng.choice([1, 2, 3, 5, 9, 13, 19, 24]), 14 * rng.choice([1, 2, 4, 7, 11, 16, 23, 30]),
+                    rng.choice(guides), rng.choice(["entire_target_object", "invisible_part_ssi"])))
+    return out
+
+
+@pytest.mark.parametrize("case", _model_cases(12, 99), ids=lambda c: f"{c[0]}-{c[1]}-B{c[2]}-{c[3]}x{c[4]}-{c[5]}-{c[6][:3]}")
+def test_model_random_sizes_against_oracle(hip, case):
+    """Non-square inputs from one patch to 336 x 420: bicubic position tables for many grids, head grids down to 1 x 1, every guide type, both
+    head activations, the raw model -- HIP path vs the fp32 oracle on the same synthetic weights, the one 1e-3 bar."""
+    from _cases import build_product_model, case_inputs, oracle_forward, rel_l1, synth_state_dict
+    i, kind, B, H, W, guide, loss = case
+    if kind == "raw":
+        spec = dict(kind="raw", encoder="vits", features=64, out_channels=[48, 96, 192, 384], B=B, H=H, W=W, seed=50 + i)
+    else:
+        spec = dict(kind="amodal", encoder="vits", guide_type=guide, loss=loss, B=B, H=H, W=W, seed=50 + i)
+    model = build_product_model(spec)
+    sd = synth_state_dict(model)
+    # centre the logits like the fixtures do, so that a sigmoid / ReLU head spans its range
+    x, grgb, mask, obs = case_inputs(spec)
+    tr = {}
+    oracle_forward(sd, spec, x, grgb, mask, obs, trace=tr)
+    key = ("" if kind == "raw" else "encoder.") + "depth_head.scratch.output_conv2.2.bias"
+    sd[key] = sd[key] - float(tr["logits"].mean()) + (1.5 if kind == "raw" else 0.0)
+    model.load_state_dict(sd, strict=True)
+    ref = oracle_forward(sd, spec, x, grgb, mask, obs)
+    model = model.cuda()
+    with torch.no_grad():
+        if kind == "raw":
+            out = model(x.cuda()).cpu()
+        else:
+            out = model(x.cuda(), guide_rgb=grgb.cuda(), guide_mask=mask.cuda(), observation=obs.cuda()).cpu()
+    assert out.shape == ref.shape and torch.isfinite(out).all()
+    err = rel_l1(out, ref)
+    print(f"{kind} B={B} {H}x{W} {guide} {loss}: rel-L1 vs oracle = {err:.3e}")
+    assert err <= 1e-3

@@ -340,7 +340,8 @@ class _GraphedForward:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread-local capture mode: other host threads may keep using the device (a serving process) while this one captures
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = eng._forward(self.x, self.guide)
 
     def __call__(self, x: torch.Tensor, guide: Optional[torch.Tensor]) -> torch.Tensor:
@@ -396,7 +397,15 @@ class DepthEngine:
         key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device))
         g = self._graphs.get(key)
         if g is None:
-            g = self._graphs[key] = _GraphedForward(self, x, guide)
+            try:
+                g = _GraphedForward(self, x, guide)
+            except RuntimeError as e:   # capture refused (e.g. an enclosing capture in another mode): same kernels, launched one by one
+                import warnings
+                warnings.warn(f"HIP-graph capture of the forward failed ({e}); this shape runs as plain launches")
+                g = False
+            self._graphs[key] = g
+        if g is False:
+            return self._forward(x, guide)
         return g(x, guide)
 
     def _forward(self, x: torch.Tensor, guide: Optional[torch.Tensor]) -> torch.Tensor:

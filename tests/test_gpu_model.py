@@ -171,6 +171,32 @@ def test_raw_vitg_1022_batch8_config5(hip):
     assert err <= TOL
 
 
+def test_graph_replay_is_bit_identical_and_follows_inputs_and_weights(hip, monkeypatch):
+    """Single-image calls replay a captured HIP graph (hip_ext/engine.py::_GraphedForward): same bits as plain launches, for every new input
+    of the captured shape, and a parameter update re-packs the weights and re-captures."""
+    from hip_ext import engine as E
+    _, meta = load_golden("vits_518")
+    case = meta["case"]
+    model = build_product_model(case)
+    model.load_state_dict(synth_state_dict(model, meta), strict=True)
+    ins = [case_inputs(case, seed=s) for s in (0, 1)]
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setattr(E, "GRAPH_MODE", mode)
+        outs[mode] = [_run_product(model, case, *i) for i in (ins[0], ins[1], ins[0])]
+    eng = model.encoder._engine()
+    assert len(eng._graphs) == 1 and all(g is not False for g in eng._graphs.values()), "the forward was not captured"
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs["1"][0], outs["1"][2]) and not torch.equal(outs["1"][0], outs["1"][1])
+    with torch.no_grad():
+        model.encoder.depth_head.scratch.output_conv2[2].bias.add_(0.25)
+    shifted = _run_product(model, case, *ins[0])
+    assert model.encoder._engine() is not eng and not torch.equal(shifted, outs["1"][0])
+    monkeypatch.setattr(E, "GRAPH_MODE", "0")
+    assert torch.equal(shifted, _run_product(model, case, *ins[0]))
+
+
 def test_state_dict_reload_repacks(hip):
     """load_state_dict after a forward must invalidate the packed operand copies."""
     _, meta = load_golden("vits_g_mask")

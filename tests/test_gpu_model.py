@@ -28,6 +28,8 @@ BATCHED = {"vitl_518_b8": 8 * 1370, "vitb_518_b8": 8 * 1370}
 
 @pytest.mark.parametrize("name", golden_names())
 def test_hip_forward_matches_reference_golden(hip, name):
+    if name == "raw_vitg_1022":
+        pytest.skip("checked by test_raw_vitg_1022_batch8_config5 on the same model object (one 1.1 G-parameter synthetic fill instead of two)")
     gold, meta = load_golden(name)
     case = meta["case"]
     model = build_product_model(case)

@@ -347,6 +347,22 @@ TILE_NAMES = {0: "256x32", 1: "128x64", 2: "256x128", 3: "256x256", 4: "128x128"
 
 
 _tile_log = None
+# bumped by every debug_set_* call: captured HIP graphs (hip_ext/engine.py) bake the kernel variant in, so they are keyed by this epoch
+_debug_epoch = 0
+
+
+def debug_epoch() -> int:
+    return _debug_epoch
+
+
+def instrumented() -> bool:
+    """True while a KernelTimer or a tile log is attached: launches must then go through the Python wrappers (no graph replay)."""
+    return _timer is not None or _tile_log is not None
+
+
+def _bump_epoch():
+    global _debug_epoch
+    _debug_epoch += 1
 
 
 def set_tile_log(log):
@@ -356,14 +372,17 @@ def set_tile_log(log):
 
 
 def debug_set_tile(cfg: int = -1):
+    _bump_epoch()
     load().ada_debug_set_tile(int(cfg))
 
 
 def debug_set_variant(v: int = 4):
+    _bump_epoch()
     load().ada_debug_set_variant(int(v))
 
 
 def debug_set_group(g: int = 0):
+    _bump_epoch()
     load().ada_debug_set_group(int(g))
 
 
@@ -372,6 +391,7 @@ def debug_last_tile() -> int:
 
 
 def debug_set_attention_variant(v: int = 5):
+    _bump_epoch()
     load().ada_debug_set_attention_variant(int(v))
 
 

@@ -19,6 +19,8 @@ from __future__ import annotations
 
 import math
 import os
+import threading
+from collections import OrderedDict
 from typing import Dict, Optional
 
 import torch
@@ -31,7 +33,7 @@ from . import bilinear as k_bilinear
 from . import dpt_tail as k_dpt_tail
 from . import igemm as k_igemm
 from . import layernorm as k_layernorm
-from . import operand_dtype
+from . import debug_epoch, instrumented, operand_dtype
 from . import patchify as k_patchify
 from . import pos_embed_resize as k_pos_embed_resize
 from . import rowstats_finalize as k_rowstats_finalize
@@ -322,6 +324,10 @@ GRAPH_MODE = os.environ.get("ADA_GRAPH", "auto")
 # "auto": graph replay for calls of up to one 518x518 image.  Measured (profiles/r02_k_hip_graph_latency_ab.txt): the forward is device-bound
 # from ViT-B upwards (replay == launches within 0.5 % at B = 1..8) and host-bound only for a single ViT-S image (3.55 -> 2.62 ms).
 GRAPH_AUTO_PIXELS = int(os.environ.get("ADA_GRAPH_AUTO_PIXELS", str(518 * 518)))
+# Bounds of the per-shape caches (LRU): a variable-resolution stream of single images must not grow device memory without limit.  A shape is
+# captured only on its SECOND sighting (a one-off resolution pays no extra warm-up forward, synchronise and empty_cache).
+MAX_GRAPHS = int(os.environ.get("ADA_GRAPH_CACHE", "4"))
+MAX_WORKSPACES = int(os.environ.get("ADA_WORKSPACE_CACHE", "6"))
 
 
 class _GraphedForward:
@@ -343,15 +349,18 @@ class _GraphedForward:
         # thread-local capture mode: other host threads may keep using the device (a serving process) while this one captures
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = eng._forward(self.x, self.guide)
+        self.lock = threading.Lock()
 
     def __call__(self, x: torch.Tensor, guide: Optional[torch.Tensor]) -> torch.Tensor:
-        self.x.copy_(x)
-        if self.guide is not None:
-            if guide is None or guide.shape != self.guide.shape:
-                raise HipExtError(f"guide tensor of shape {tuple(self.guide.shape)} required")
-            self.guide.copy_(guide)
-        self.graph.replay()
-        return self.out.clone()
+        # the static input / output buffers are shared by every caller of this shape: copy-in, replay and copy-out are one critical section
+        with self.lock:
+            self.x.copy_(x)
+            if self.guide is not None:
+                if guide is None or guide.shape != self.guide.shape:
+                    raise HipExtError(f"guide tensor of shape {tuple(self.guide.shape)} required")
+                self.guide.copy_(guide)
+            self.graph.replay()
+            return self.out.clone()
 
 
 class DepthEngine:
@@ -361,8 +370,9 @@ class DepthEngine:
         self.w = weights
         self.final_act = {"sigmoid": ACT_SIGMOID, "relu": ACT_RELU, "none": ACT_NONE}[final_act]
         self.normalise_input = normalise_input
-        self._ws: Dict[tuple, Workspace] = {}
-        self._graphs: Dict[tuple, "_GraphedForward"] = {}
+        self._ws: "OrderedDict[tuple, Workspace]" = OrderedDict()
+        self._graphs: "OrderedDict[tuple, object]" = OrderedDict()   # key -> _GraphedForward | False (capture refused) | int (sightings)
+        self._lock = threading.Lock()
 
     def max_batch(self, H: int, W: int) -> int:
         if H * W > MAX_ROWS:
@@ -374,8 +384,12 @@ class DepthEngine:
         key = (B, H, W, str(device))
         ws = self._ws.get(key)
         if ws is None:
+            while len(self._ws) >= max(1, MAX_WORKSPACES):
+                self._ws.popitem(last=False)      # least recently used shape; a captured graph keeps its own workspace alive
             ws = Workspace(self.w, B, H, W, device)
             self._ws[key] = ws
+        else:
+            self._ws.move_to_end(key)
         return ws
 
     # ---- small helpers over igemm ---------------------------------------------------------
@@ -392,18 +406,30 @@ class DepthEngine:
             raise HipExtError("DepthEngine.forward: input must live on a HIP device (no CPU fallback in the product path)")
         mode = GRAPH_MODE
         use = mode == "1" or (mode == "auto" and x.shape[0] * x.shape[-2] * x.shape[-1] <= GRAPH_AUTO_PIXELS)
-        if not use or torch.cuda.is_current_stream_capturing():
+        # replay bypasses the Python wrappers: with a KernelTimer or a tile log attached the launches must be issued one by one
+        if not use or instrumented() or torch.cuda.is_current_stream_capturing():
             return self._forward(x, guide)
-        key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device))
-        g = self._graphs.get(key)
-        if g is None:
-            try:
-                g = _GraphedForward(self, x, guide)
-            except RuntimeError as e:   # capture refused (e.g. an enclosing capture in another mode): same kernels, launched one by one
-                import warnings
-                warnings.warn(f"HIP-graph capture of the forward failed ({e}); this shape runs as plain launches")
-                g = False
-            self._graphs[key] = g
+        # the kernel variant / tile override / fused-tail switch in force at capture time are baked into the graph
+        key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device), debug_epoch(), FUSED_TAIL)
+        with self._lock:
+            g = self._graphs.get(key)
+            if g is not None:
+                self._graphs.move_to_end(key)
+            if g is None or isinstance(g, int):
+                seen = (g or 0) + 1
+                if mode != "1" and seen < 2:       # first sighting of this shape: plain launches, capture when it comes back
+                    self._graphs[key] = seen
+                    g = False
+                else:
+                    try:
+                        g = _GraphedForward(self, x, guide)
+                    except RuntimeError as e:   # capture refused (e.g. an enclosing capture in another mode): same kernels, launched one by one
+                        import warnings
+                        warnings.warn(f"HIP-graph capture of the forward failed ({e}); this shape runs as plain launches")
+                        g = False
+                    self._graphs[key] = g
+                while len(self._graphs) > max(1, MAX_GRAPHS):
+                    self._graphs.popitem(last=False)
         if g is False:
             return self._forward(x, guide)
         return g(x, guide)

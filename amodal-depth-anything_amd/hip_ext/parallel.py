@@ -7,8 +7,10 @@ so weights are replicated and the only exchange is the output gather: [B_local, 
 
 ``DepthGather`` owns the pre-sized buffers of that exchange and is the ONE collective path of this package:
 ``sharded_forward`` (global batch in, global batch out), ``bench.py --gpus N`` (per-rank synthetic shards, asynchronous
-gather riding under the next forward) and ``src/scripts/amodal_dav2_inference.py`` (dataset sharded over ranks) all go
-through it.  No pickled metadata, no per-call allocation: shard sizes follow from (batch, world) alone.
+gather riding under the next forward) go through it; ``src/scripts/amodal_dav2_inference.py`` shards its sample list with the same
+``shard_range`` and combines per-sample metric sums with one all-reduce (it writes files, it gathers no maps).
+No pickled metadata, no per-call allocation: shard sizes follow from (batch, world) alone, and the item shape / dtype are DECLARED
+(every rank, also one with an empty shard, builds the same buffers) and checked against what the forward returned.
 """
 from __future__ import annotations
 
@@ -41,6 +43,9 @@ class DepthGather:
     def __init__(self, batch: int, item_shape: Sequence[int], dtype: torch.dtype, device, group=None):
         self.group = group
         self.rank, self.world = _world(group)
+        # an initialised process group always takes the collective path, also with ONE rank (the 1-rank `nccl` group of the GPU suite
+        # pushes a real model output through RCCL this way)
+        self._collective = dist.is_available() and dist.is_initialized()
         self.batch, self.item_shape = int(batch), tuple(int(s) for s in item_shape)
         self.spans: List[Tuple[int, int]] = [shard_range(self.batch, r, self.world) for r in range(self.world)]
         self.lo, self.hi = self.spans[self.rank]
@@ -58,8 +63,11 @@ class DepthGather:
         if n > 0:
             assert local is not None and tuple(local.shape) == (n,) + self.item_shape, \
                 f"rank {self.rank}: expected {(n,) + self.item_shape}, got {None if local is None else tuple(local.shape)}"
-        if self.world == 1:
-            self.recv[:n].copy_(local)
+        if n > 0:
+            assert local.dtype == self.recv.dtype, f"rank {self.rank}: gather declared {self.recv.dtype}, got {local.dtype}"
+        if not self._collective:   # no process group: the "gather" of one rank is a copy into the result buffer
+            if n > 0:
+                self.recv[:n].copy_(local)
             return
         if self.even:
             src = local.contiguous()
@@ -98,7 +106,9 @@ def sharded_forward(forward: Callable[..., torch.Tensor], inputs: Sequence[Optio
 
     ``inputs`` are the *global* batch tensors (``None`` entries are passed through).  ``item_shape`` / ``dtype`` describe
     one output item; they default to the depth-map convention of this package, ``[1, H, W]`` fp32 with H, W the trailing
-    dims of the first input -- every rank can derive them locally, including a rank whose shard is empty."""
+    dims of the first input -- every rank derives them locally, including a rank whose shard is empty.  A forward with another
+    output convention (the raw model's ``[B, H, W]``, a half-precision output) must pass them: a mismatch raises on the rank
+    that sees it instead of building different collective buffers on different ranks."""
     rank, world = _world(group)
     first = next(t for t in inputs if t is not None)
     batch = first.shape[0]
@@ -106,12 +116,14 @@ def sharded_forward(forward: Callable[..., torch.Tensor], inputs: Sequence[Optio
     local = None
     if hi > lo:
         local = forward(*[None if t is None else t[lo:hi] for t in inputs])
-    if world == 1 or not gather:
+    if not gather or not (dist.is_available() and dist.is_initialized()):
         return local
     if item_shape is None:
-        item_shape = tuple(local.shape[1:]) if local is not None else (1,) + tuple(first.shape[-2:])
-    if local is not None:
-        dtype = local.dtype
+        item_shape = (1,) + tuple(first.shape[-2:])
+    item_shape = tuple(int(v) for v in item_shape)
+    if local is not None and (tuple(local.shape[1:]) != item_shape or local.dtype != dtype):
+        raise ValueError(f"sharded_forward: the forward returned items of shape {tuple(local.shape[1:])} / {local.dtype} but "
+                         f"{item_shape} / {dtype} was declared (pass item_shape= / dtype= for other output conventions)")
     key = (batch, tuple(item_shape), dtype, str(first.device), id(group))
     g = _gathers.get(key)
     if g is None:

@@ -20,6 +20,7 @@
 //   V transpose reads BEFORE the softmax so they land behind it (hipcc sinks each ds_read next to its MFMA otherwise).
 //   N = 1370 is not a multiple of 64: the last tile masks keys >= N to -inf.
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include "ada_common.h"
@@ -46,44 +47,16 @@ ADA_DEV void half_exchange(float x, float& lo, float& hi_) {
     hi_ = __builtin_bit_cast(float, b);
 }
 
-// Row sum of P.  ADA_ROWSUM 0: v_dot2c_f32_f16 on the packed pair (round 1); 1: two fp32 adds of the unrounded exponentials;
-// 2: v_pk_add_f16 into a packed fp16 accumulator (per tile), folded into the fp32 sum once per tile.  Beside an MFMA the dot2c
-// form costs ~13 ns per slot, the two adds ~5, the packed add ~1 (tools/ubench/softmax_slot.hip, profiles/r02_a_softmax_slot_ubench.txt).
-#ifndef ADA_ROWSUM
-#define ADA_ROWSUM 1
-#endif
+// Row sum of P: two fp32 adds of the unrounded exponentials per pair.  (v_dot2c_f32_f16 on the packed pair and v_pk_add_f16 into a packed
+// accumulator were A/B-ed in round 2 -- tools/ubench/softmax_slot.hip, profiles/r02_a_softmax_slot_ubench.txt -- no difference in the kernel.)
 struct RowSum {
     float a0 = 0.0f, a1 = 0.0f;
-    opx2 h = {(op_t)0.0f, (op_t)0.0f};
-    ADA_DEV void add(float e0, float e1, opx2 pp, bool odd);
-    ADA_DEV float total() const {
-#if ADA_ROWSUM == 2
-        return (float)h[0] + (float)h[1];
-#else
-        return a0 + a1;
-#endif
+    ADA_DEV void add(float e0, float e1, opx2, bool) {
+        a0 += e0;
+        a1 += e1;
     }
+    ADA_DEV float total() const { return a0 + a1; }
 };
-ADA_DEV float dot2_acc(opx2 p, float acc) {
-#ifdef ADA_OPERAND_BF16
-    return acc + (float)p[0] + (float)p[1];
-#else
-    const opx2 ones = {(op_t)1.0f, (op_t)1.0f};
-    return __builtin_amdgcn_fdot2(p, ones, acc, false);
-#endif
-}
-
-ADA_DEV void RowSum::add(float e0, float e1, opx2 pp, bool odd) {
-#if ADA_ROWSUM == 0
-    if (odd) a1 = dot2_acc(pp, a1);
-    else a0 = dot2_acc(pp, a0);
-#elif ADA_ROWSUM == 1
-    a0 += e0;
-    a1 += e1;
-#else
-    h = h + pp;
-#endif
-}
 
 __global__ __launch_bounds__(256, 2) void attention_kernel_v3(const op_t* __restrict__ qkv, op_t* __restrict__ out,
                                                            int n_tok, int heads, int nqb, int n_bh) {
@@ -307,343 +280,6 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_v3(const op_t* __rest
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v4[e] = to_op(o[db][g * 4 + e] * inv);
                 *(opx4*)(orow + db * 32 + 8 * g + 4 * hi) = v4;
-            }
-        }
-    }
-}
-
-
-// =====================================================================================================================
-// attention_kernel_pp -- 8-wave "ping-pong" kernel (the default).
-//
-// One workgroup = 8 waves = 128 query rows of one (batch, head) x TWO key streams: wave w works on query group
-// qg = w & 3 (32 rows, as in v3) and key half kh = w >> 2 -- half 0 walks the even 64-key tiles, half 1 the odd ones, each
-// with its own online-softmax state; the two partial results (O, m, l) are merged through LDS at the end.  Waves w and
-// w + 4 share a SIMD (MI355X_MICROARCH.md "Two waves per SIMD"), and half 1 runs one barrier interval behind half 0, so on
-// every SIMD one wave is in its matrix interval while its partner is in its softmax interval:
-//
-//     M interval (tile j):  [4 LDS-DMA copies: K(j+2), V(j+1)]  8 MFMAs  O += V(j-1)^T P(j-1)   8 MFMAs  S = K(j) Q^T - m
-//     V interval (tile j):  [24 LDS reads: V(j) -> registers, K(j+1) -> registers]   softmax: S -> P(j), l, (rescale O)
-//
-// so the MFMA pipe sees 16 back-to-back MFMAs per interval with no LDS or VALU dependency inside them (operands were
-// fetched during the previous softmax), and the softmax VALU stream runs beside the partner's MFMAs.  v3 ran every wave
-// through load -> QK -> softmax -> PV in sequence and relied on unsynchronised co-resident workgroups for overlap: the
-// MFMA pipe was 42 % busy (profiles/r01_c_pmc_summary.json).
-//
-// Other changes against v3: the running max enters the MFMA chain as its C operand (a 16-register block holding -m)
-// instead of an extra k-step, so all 16 MFMAs per tile are useful work; K/V tiles are copied by buffer_load ... lds with
-// the tile offset in the scalar operand (no 64-bit address arithmetic per tile) and out-of-range keys are zero-filled by
-// the buffer bounds check instead of being clamped.
-// LDS: per half 2 x (K 8 KB) + 2 x (V 8 KB) = 32 KB, 64 KB per workgroup, one workgroup per CU (<= 256 VGPRs, 2 waves/SIMD).
-// =====================================================================================================================
-constexpr int PP_HALF_BYTES = 2 * K_TILE + 2 * V_TILE;   // 32 KB: [K0 | K1 | V0 | V1]
-
-template <bool PRIO, bool PROF = false>
-__global__ __launch_bounds__(512, 2) void attention_kernel_pp(const op_t* __restrict__ qkv, op_t* __restrict__ out,
-                                                              int n_tok, int heads, int nqb, int n_bh, unsigned long long* prof = nullptr) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * PP_HALF_BYTES];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qg = wave & 3;     // query group (32 rows)
-    const int kh = wave >> 2;    // key half: tiles kh, kh + 2, kh + 4, ...
-    const int l31 = lane & 31;
-    const int hi = lane >> 5;
-
-    int bh, qb;
-    {
-        const int nblk = gridDim.x, bid = blockIdx.x;
-        const int q = nblk >> 3, r = nblk & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        bh = logical / nqb;
-        qb = logical - bh * nqb;
-    }
-    const int b = bh / heads, h = bh - b * heads;
-    const long D = (long)heads * HD;
-    const long row_stride = 3 * D;
-    const op_t* base = qkv + (long)b * n_tok * row_stride + (long)h * HD;
-    const op_t* qptr = base;
-
-    // K / V windows of this (batch, head): a raw buffer resource that ends with the last token's 128-byte row segment, so
-    // keys >= n_tok read as zero
-    const unsigned win_bytes = (unsigned)((long)(n_tok - 1) * row_stride * 2 + HD * 2);
-    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + D), 0, (int)win_bytes, 0x20000);
-    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + 2 * D), 0, (int)win_bytes, 0x20000);
-
-    const int q_row = qb * QBLK + qg * 32 + l31;
-    const int q_ld = q_row < n_tok ? q_row : n_tok - 1;
-    const bool wave_active = (qb * QBLK + qg * 32) < n_tok;   // wave-uniform
-    opx8 qf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *(const opx8*)(qptr + (long)q_ld * row_stride + 16 * s + 8 * hi);
-
-    // ---- staging: the 256 lanes of a half copy one 64-key tile of K (or V) in two passes of 32 rows; lane-linear LDS image,
-    //      bank swizzles on the SOURCE chunk exactly as in v3
-    const int th = tid & 255;
-    const int srow = th >> 3, sc = th & 7;
-    const unsigned row_bytes = (unsigned)(row_stride * 2);
-    const unsigned k_voff = (unsigned)srow * row_bytes + (unsigned)((sc ^ ((srow >> 1) & 7)) * 16);
-    const unsigned v_voff = (unsigned)srow * row_bytes + (unsigned)((sc ^ (((srow >> 1) & 1) << 2)) * 16);
-    const unsigned pass_bytes = 32u * row_bytes;
-    char* const half_lds = smem + kh * PP_HALF_BYTES + qg * 1024;
-    // The tile offset goes into the VECTOR offset: the hardware bounds check covers voffset + immediate only (the scalar
-    // offset is excluded), and the zero fill of keys >= n_tok relies on that check.
-    auto stage_k = [&](int buf, int tile) {    // tile = global 64-key tile index
-        const unsigned so = (unsigned)tile * 2u * pass_bytes;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(half_lds + buf * K_TILE), 16, (int)(k_voff + so), 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(half_lds + buf * K_TILE + 4096), 16, (int)(k_voff + so + pass_bytes), 0, 0, 0);
-    };
-    auto stage_v = [&](int buf, int tile) {
-        const unsigned so = (unsigned)tile * 2u * pass_bytes;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(half_lds + 2 * K_TILE + buf * V_TILE), 16, (int)(v_voff + so), 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(half_lds + 2 * K_TILE + buf * V_TILE + 4096), 16, (int)(v_voff + so + pass_bytes), 0, 0, 0);
-    };
-
-    f32x16 o[2], negm;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] = 0.0f; o[1][r] = 0.0f; negm[r] = 0.0f; }
-    float m_run = 0.0f, l_run = 0.0f;      // base-2 running max / row sum of this key half
-    constexpr float RESCALE_THR = 8.0f;
-
-    // LDS fragment addresses (byte offsets; buffer / row-block offsets are immediates of the reads)
-    const unsigned half0 = (unsigned)(size_t)smem + (unsigned)(kh * PP_HALF_BYTES);
-    const int swz = (l31 >> 1) & 7;
-    unsigned kofs[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) kofs[s] = half0 + l31 * ROWB + (((2 * s + hi) ^ swz) * 16);
-    const int i16 = lane & 15;
-    const int g1 = (lane >> 4) & 1;
-    const int vsw = (i16 >> 3) & 1;
-    const unsigned v_row_part = half0 + 2 * K_TILE + (4 * hi + (i16 >> 2)) * ROWB + (16 * g1 + 4 * (i16 & 3)) * 2;
-    const unsigned vofs0 = v_row_part + (vsw ? 64u : 0u), vofs1 = v_row_part + (vsw ? 0u : 64u);
-
-    const int nt = (n_tok + KVB - 1) / KVB;
-    const int jmax = (nt + 1) >> 1;          // intervals per half (uniform over the workgroup: barrier counts must match)
-
-    opx8 kf[2][4];
-    opx4 vlo[2][2][2], vhi[2][2][2];
-    opx8 pf[2][2];
-    f32x16 sT[2];
-
-    // ---- prologue: K(0), V(0), K(1) of this half; K(0) fragments into registers ----------------
-    stage_k(0, kh);
-    stage_v(0, kh);
-    stage_k(1, kh + 2);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])::"memory");   // also pins the Q loads' wait here, outside the loop
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[kb][s]) : "v"(kofs[s]), "i"(kb * 32 * ROWB));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();            // every wave holds its K(0) fragments: buffer K0 may be refilled
-    if (kh == 1) __builtin_amdgcn_s_barrier();   // half 1 runs one interval behind half 0
-    if (PRIO && kh == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the younger half (T5 static form)
-
-    // PROF: s_memtime stamps per wave -- [0] matrix interval up to the last MFMA issue, [1] vmcnt wait, [2] barrier wait,
-    // [3] softmax interval incl. the fragment-read wait, [4] barrier wait
-    unsigned long long tp[5] = {0, 0, 0, 0, 0}, t_prev = 0;
-    auto stamp = [&](int k) {
-        if constexpr (PROF) {
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            tp[k] += t - t_prev;
-            t_prev = t;
-        }
-    };
-    if constexpr (PROF) t_prev = __builtin_amdgcn_s_memtime();
-    auto m_interval = [&](auto parity, int j) {
-        constexpr int P = decltype(parity)::value;     // j & 1
-        const int tile = 2 * j + kh;
-        stage_k(P, tile + 4);                // K(j+2) -> K buffer j&1 (last read in the previous softmax interval)
-        stage_v(P ^ 1, tile + 2);            // V(j+1) -> V buffer (j+1)&1
-        __builtin_amdgcn_sched_barrier(0);
-        if (wave_active) {
-            if (j > 0 && tile - 2 < nt) {    // O^T += V(j-1)^T P(j-1)^T
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int db = 0; db < 2; ++db) {
-                            const opx4 lo = vlo[kb][s][db], hi4 = vhi[kb][s][db];
-                            opx8 vf;
-                            vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                            vf[4] = hi4[0]; vf[5] = hi4[1]; vf[6] = hi4[2]; vf[7] = hi4[3];
-                            o[db] = mfma32(vf, pf[kb][s], o[db]);
-                        }
-            }
-            if (tile < nt) {                 // S^T = K(j) Q^T - m (running max as the C operand of the first k-step)
-                sT[0] = mfma32(kf[0][0], qf[0], negm);
-                sT[1] = mfma32(kf[1][0], qf[0], negm);
-#pragma unroll
-                for (int s = 1; s < 4; ++s) {
-                    sT[0] = mfma32(kf[0][s], qf[s], sT[0]);
-                    sT[1] = mfma32(kf[1][s], qf[s], sT[1]);
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        stamp(0);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the copies issued one interval ago (K(j+1), V(j)) have landed
-        stamp(1);
-        __builtin_amdgcn_s_barrier();
-        stamp(2);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    auto v_interval = [&](auto parity, int j) {
-        constexpr int P = decltype(parity)::value;
-        const int tile = 2 * j + kh;
-        // operands of the NEXT matrix interval: V(j) (transpose reads) and K(j+1); they land behind the softmax below
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[kb][s][0]) : "v"(vofs0), "i"(P * V_TILE + (kb * 32 + s * 16) * ROWB));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[kb][s][0]) : "v"(vofs0), "i"(P * V_TILE + (kb * 32 + s * 16 + 8) * ROWB));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[kb][s][1]) : "v"(vofs1), "i"(P * V_TILE + (kb * 32 + s * 16) * ROWB));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[kb][s][1]) : "v"(vofs1), "i"(P * V_TILE + (kb * 32 + s * 16 + 8) * ROWB));
-            }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[kb][s]) : "v"(kofs[s]), "i"((P ^ 1) * K_TILE + kb * 32 * ROWB));
-        if (wave_active && tile < nt) {
-            if (tile == nt - 1) {            // mask keys beyond the sequence (wave-uniform branch)
-                const int kv0 = tile * KVB;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (kv0 + kb * 32 + crow32(r, hi) >= n_tok) sT[kb][r] = -INFINITY;
-            }
-            float mx = sT[0][0];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = __builtin_fmaxf(mx, sT[kb][r]);
-            {
-                float a, b2;
-                half_exchange(mx, a, b2);
-                mx = __builtin_fmaxf(a, b2);
-            }
-            if (j == 0 || __any(mx > RESCALE_THR)) {
-                const bool mv = (j == 0) || (mx > RESCALE_THR);
-                const float m_new = mv ? m_run + mx : m_run;
-                const float delta = m_new - m_run;
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
-                l_run *= alpha;
-                m_run = m_new;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) negm[r] = -m_new;
-#pragma unroll
-                for (int db = 0; db < 2; ++db)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sT[kb][r] -= delta;
-            }
-            RowSum rs;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    opx2 pp;
-                    const float e0 = __builtin_amdgcn_exp2f(sT[kb][r]), e1 = __builtin_amdgcn_exp2f(sT[kb][r + 1]);
-                    pp[0] = (op_t)e0;
-                    pp[1] = (op_t)e1;
-                    pf[kb][r >> 3][r & 7] = pp[0];
-                    pf[kb][r >> 3][(r & 7) + 1] = pp[1];
-                    rs.add(e0, e1, pp, (r & 2) != 0);
-                }
-            }
-            l_run += rs.total();
-        }
-        // the fragment reads above must have returned before any wave of this half refills the buffers they came from
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]));
-        asm volatile("" : "+v"(vlo[0][0][0]), "+v"(vlo[0][0][1]), "+v"(vlo[0][1][0]), "+v"(vlo[0][1][1]), "+v"(vlo[1][0][0]), "+v"(vlo[1][0][1]), "+v"(vlo[1][1][0]), "+v"(vlo[1][1][1]));
-        asm volatile("" : "+v"(vhi[0][0][0]), "+v"(vhi[0][0][1]), "+v"(vhi[0][1][0]), "+v"(vhi[0][1][1]), "+v"(vhi[1][0][0]), "+v"(vhi[1][0][1]), "+v"(vhi[1][1][0]), "+v"(vhi[1][1][1]));
-        __builtin_amdgcn_sched_barrier(0);
-        stamp(3);
-        __builtin_amdgcn_s_barrier();
-        stamp(4);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    for (int j = 0; j < jmax; j += 2) {
-        m_interval(std::integral_constant<int, 0>{}, j);
-        v_interval(std::integral_constant<int, 0>{}, j);
-        if (j + 1 < jmax) {
-            m_interval(std::integral_constant<int, 1>{}, j + 1);
-            v_interval(std::integral_constant<int, 1>{}, j + 1);
-        }
-    }
-    // ---- last P V of this half ------------------------------------------------------------------
-    if (wave_active && 2 * (jmax - 1) + kh < nt) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const opx4 lo = vlo[kb][s][db], hi4 = vhi[kb][s][db];
-                    opx8 vf;
-                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                    vf[4] = hi4[0]; vf[5] = hi4[1]; vf[6] = hi4[2]; vf[7] = hi4[3];
-                    o[db] = mfma32(vf, pf[kb][s], o[db]);
-                }
-    }
-    if constexpr (PROF) {
-        if (lane == 0 && prof) {
-            unsigned long long* d = prof + ((long)blockIdx.x * 8 + wave) * 8;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) d[k] = tp[k];
-            d[5] = (unsigned long long)jmax;
-        }
-    }
-    if (PRIO && kh == 1) __builtin_amdgcn_s_setprio(0);
-    if (kh == 0) __builtin_amdgcn_s_barrier();       // balances half 1's extra barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // run-ahead copies (zero-filled tiles beyond the sequence) are done with LDS
-    __builtin_amdgcn_s_barrier();
-
-    // ---- merge the two key halves through LDS: half 1 publishes (O, m, l), half 0 combines, normalises and stores --------
-    float* xch = (float*)smem + qg * 64 + lane;       // slot r of this (query group, lane): xch[r * 256]
-    const bool has1 = (1 < nt);                       // half 1 saw at least one tile (uniform)
-    if (kh == 1) {
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xch[(db * 16 + r) * 256] = o[db][r];
-        xch[32 * 256] = has1 ? m_run : -1.0e30f;
-        xch[33 * 256] = l_run;
-    }
-    __syncthreads();
-    if (kh == 0) {
-        const float m1 = xch[32 * 256], l1 = xch[33 * 256];
-        const float m = __builtin_fmaxf(m_run, m1);
-        const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
-        float l_lo, l_hi;
-        half_exchange(l_run * a0 + l1 * a1, l_lo, l_hi);
-        const float inv = 1.0f / (l_lo + l_hi);
-        const float w0 = a0 * inv, w1 = a1 * inv;
-        if (q_row < n_tok) {
-            op_t* orow = out + ((long)b * n_tok + q_row) * D + (long)h * HD;
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    opx4 v4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v4[e] = to_op(o[db][g * 4 + e] * w0 + xch[(db * 16 + g * 4 + e) * 256] * w1);
-                    *(opx4*)(orow + db * 32 + 8 * g + 4 * hi) = v4;
-                }
             }
         }
     }
@@ -951,16 +587,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_mix(const op_t* __res
 
 }  // namespace
 
-static int g_attn_variant = 5;   // 5: mixed-stream kernel (default); 0: ping-pong, 1: ping-pong without static priority, 2: profiled ping-pong, 3: round-1 kernel (v3)
-static unsigned long long* g_attn_prof = nullptr;
-extern "C" void ada_debug_set_attention_variant(int v) { g_attn_variant = v; }
-extern "C" void ada_debug_set_attention_profile(void* dev_buf) { g_attn_prof = (unsigned long long*)dev_buf; }
+// 5: mixed-stream kernel (default); 3: the round-1 kernel (load -> QK^T -> softmax -> PV in sequence), kept as the one alternate.
+// (An 8-wave split-KV ping-pong kernel was built and measured in round 2 -- within 5 % of the other two, profiles/r02_a_attention_pp_* --
+// and removed from the build in round 3.)
+static std::atomic<int> g_attn_variant{5};
+extern "C" void ada_debug_set_attention_variant(int v) { g_attn_variant.store(v == 3 ? 3 : 5, std::memory_order_relaxed); }
 
 extern "C" int ada_attention_fwd(const void* qkv, void* out, int32_t batch, int32_t n_tokens, int32_t heads, void* stream) {
     static std::once_flag env_once;   // ADA_ATTN_VARIANT presets the kernel choice once (same meaning as ada_debug_set_attention_variant)
     std::call_once(env_once, []() {
         const char* e = getenv("ADA_ATTN_VARIANT");
-        if (e) g_attn_variant = atoi(e);
+        if (e) ada_debug_set_attention_variant(atoi(e));
     });
     ADA_REQUIRE(qkv && out, ADA_EINVAL, "ada_attention_fwd: null pointer");
     ADA_REQUIRE(batch > 0 && n_tokens > 0 && heads > 0, ADA_EINVAL, "ada_attention_fwd: bad shape B=%d N=%d H=%d", batch, n_tokens, heads);
@@ -969,20 +606,11 @@ extern "C" int ada_attention_fwd(const void* qkv, void* out, int32_t batch, int3
     const long nblk = (long)nqb * batch * heads;
     ADA_REQUIRE(nblk < (1L << 31), ADA_EUNSUPPORTED, "ada_attention_fwd: grid too large");
     ADA_REQUIRE((long)n_tokens * 3 * heads * HD * 2 < (1L << 31), ADA_EUNSUPPORTED, "ada_attention_fwd: one image's qkv rows exceed the 2 GiB buffer window");
-    if (g_attn_variant == 3)
+    if (g_attn_variant.load(std::memory_order_relaxed) == 3)
         hipLaunchKernelGGL(attention_kernel_v3, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const op_t*)qkv, (op_t*)out,
                            n_tokens, heads, nqb, batch * heads);
-    else if (g_attn_variant == 5)
+    else
         hipLaunchKernelGGL(attention_kernel_mix, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const op_t*)qkv, (op_t*)out,
                            n_tokens, heads, nqb, batch * heads);
-    else if (g_attn_variant == 2)
-        hipLaunchKernelGGL((attention_kernel_pp<true, true>), dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, (const op_t*)qkv, (op_t*)out,
-                           n_tokens, heads, nqb, batch * heads, g_attn_prof);
-    else if (g_attn_variant == 1)
-        hipLaunchKernelGGL(attention_kernel_pp<false>, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, (const op_t*)qkv, (op_t*)out,
-                           n_tokens, heads, nqb, batch * heads, (unsigned long long*)nullptr);
-    else
-        hipLaunchKernelGGL(attention_kernel_pp<true>, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, (const op_t*)qkv, (op_t*)out,
-                           n_tokens, heads, nqb, batch * heads, (unsigned long long*)nullptr);
     return ada_check_launch("ada_attention_fwd");
 }

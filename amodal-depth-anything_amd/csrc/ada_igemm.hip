@@ -5,10 +5,11 @@
 // chip's power cap.  Tile shapes:
 //     256 x 256 x 64, 8 waves (2 x 4), wave tile 128 x 64  -- the default: 1 workgroup / CU, 128 FLOP per LDS byte staged
 //     128 x 128 x 64, 4 waves, two workgroups per CU        -- N <= 128 (output_conv1, ViT-B head) and mid-size problems
-//     512 x 128 x 64 / 256 x 128 x 64, 8 waves             -- selectable (ADA_IGEMM_TILE=7 / 2); measured slower than 128 x 128 at N = 128
+//     256 x 128 x 64, 8 waves                              -- mid-size problems (picked by the quantised time estimate)
 //     128 x 64 x 64 / 256 x 32 x 64, 4 waves                 -- small problems (single images, ViT-S/B at small batch: chosen by a
 //                                                            quantised time estimate) and narrow outputs (32-channel tail conv)
-//     128 x 256 x 32, 4 waves                              -- A/B only (ADA_IGEMM_SHORTK=5): co-resident workgroups measured slower
+//     (512 x 128 x 64 and a 128 x 256 x 32 tile with co-resident workgroups were A/B-ed in rounds 1-3 -- 10-15 % slower on every
+//      ViT-L shape, profiles/r03_a_tile_ab.txt -- and are no longer built.)
 // A and W k-slabs (rows of BK operands = 128 or 64 B) go HBM/L2 -> LDS with 16-byte buffer loads to LDS (buffer_load_dwordx4 ... lds,
 // no VGPR round trip), two LDS stages, one barrier per k-step; the loads of slab t+1 are in flight during the MFMAs of slab t.
 // LDS rows are stored linearly (the LDS-DMA writes wave base + lane*16) but each lane *fetches* chunk
@@ -23,6 +24,7 @@
 // fp32 (16 B) and operand-typed (8 B) stores are contiguous 128-256 B row segments.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include "ada_common.h"
@@ -539,10 +541,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             if (p.dbg && kt == 0) t_first = __builtin_amdgcn_s_memtime();
             // The two waves that share a SIMD (w and w+4 of an 8-wave workgroup) leave the barrier together; if both issued
             // their global->LDS copies first, neither would have MFMAs in flight for a few hundred cycles.  One group therefore
-            // issues its copies after the first 32-wide half of the slab (they still have half a k-step to land).  Variant 4
-            // (default): waves 0-3 are the late group; variant 1: waves 4-7; 0: nobody (-3 %); 2: everybody (-5 % on long K).
-            // Variant 4 over 1: qkv -1.7 %, fc2 -3 %, end to end +1.6 % (profiles/r01_l_gemm_copy_stagger_variants.txt).
-            const bool late = (NWAVES == 8) && ((p.variant == 1 && wave >= 4) || p.variant == 2 || (p.variant == 4 && wave < 4));
+            // issues its copies after the first 32-wide half of the slab (they still have half a k-step to land).  Waves 0-3 are
+            // the late group (waves 4-7 late: qkv +1.7 %, fc2 +3 % slower; nobody: -3 %; everybody: -5 % on long K --
+            // profiles/r01_l_gemm_copy_stagger_variants.txt).
+            const bool late = (NWAVES == 8) && wave < 4;
             const bool more = kt + 1 < nk;
             long aoff = 0, boff = 0;
             if (more) slab_offsets(kt + 1, aoff, boff);
@@ -1037,7 +1039,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     }
 }
 
-static int g_group_override = 0;  // debug: force the column-group width (0 = model)
+static std::atomic<int> g_group_override{0};  // debug: force the column-group width (0 = model)
 static thread_local int g_last_tile = -1;   // tile configuration of the calling thread's most recent launch (ada_debug_last_tile)
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, int LOOP = 0>
@@ -1060,7 +1062,8 @@ int launch_cfg(IgemmDev& d, hipStream_t stream) {
             const double est = groups * a_bytes + 8.0 * w_bytes;
             if (est < 0.9 * best) { best = est; gbest = g; }
         }
-        d.group_n = g_group_override > 0 ? (g_group_override < d.tiles_n ? g_group_override : d.tiles_n) : gbest;
+        const int go = g_group_override.load(std::memory_order_relaxed);
+        d.group_n = go > 0 ? (go < d.tiles_n ? go : d.tiles_n) : gbest;
     }
     auto kern = igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, EPI, LOOP>;
     static std::once_flag attr_once;   // one per template instantiation; concurrent first calls are serialised
@@ -1069,15 +1072,13 @@ int launch_cfg(IgemmDev& d, hipStream_t stream) {
             (void)hipGetLastError();
         }
     });
-    g_last_tile = (BM == 256 && BN == 32 ? 0 : BM == 128 && BN == 64 ? 1 : BM == 256 && BN == 128 ? 2 : BM == 256 && BN == 256 ? 3 :
-                   BM == 128 && BN == 128 ? 4 : BM == 128 && BN == 256 ? 5 : 7) + 100 * LOOP;
+    g_last_tile = (BM == 256 && BN == 32 ? 0 : BM == 128 && BN == 64 ? 1 : BM == 256 && BN == 128 ? 2 : BM == 256 && BN == 256 ? 3 : 4) + 100 * LOOP;
     const long nblk = (long)d.tiles_m * d.tiles_n;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), SMEM, stream, d);
     return ada_check_launch("ada_igemm");
 }
 
-// tile configurations: 0: 256x32, 1: 128x64, 2: 256x128, 3: 256x256 (1 WG/CU), 4: 128x128, 5: 128x256x32 (2-3 WG/CU),
-// 7: 512x128 (8 waves x 64x128, all 160 KiB of LDS)
+// tile configurations: 0: 256x32, 1: 128x64, 2: 256x128, 3: 256x256 (1 WG/CU), 4: 128x128 (2 WG/CU)
 // Relative time of launching `tiles` workgroups of a BMxBN tile with `occ` workgroups resident per CU and main-loop
 // efficiency `eff` (measured, relative to the 256x256 tile): whole rounds of 256*occ tiles, co-resident tiles share a CU.
 static inline double tile_time(long M, long N, int bm, int bn, int occ, double eff) {
@@ -1089,7 +1090,7 @@ static inline double tile_time(long M, long N, int bm, int bn, int occ, double e
 }
 
 template <int EPI>
-int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
+int launch_epi(IgemmDev& d, hipStream_t s, int force) {
     int cfg;
     if (d.N <= 32) cfg = 0;
     else if (d.N <= 64) cfg = 1;
@@ -1097,7 +1098,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
     else {
         // large problems: the 256x256 tile (best MFMA efficiency); small ones (single images, ViT-S/B at small batch)
         // would leave most CUs idle with it, so pick the tile that minimises the quantised time estimate
-        cfg = (d.K <= 2048) ? short_k_cfg : 3;
+        cfg = 3;
         double best = tile_time(d.M, d.N, 256, 256, 1, 1.0);
         // relative main-loop efficiencies re-fitted after the move to 16x16x32 MFMAs (tools/autotune_shapes.py at B = 1 and 4:
         // the 128x64 tile with three co-resident workgroups wins more of the small problems than it used to)
@@ -1108,10 +1109,11 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
         if (EPI != EPI_SWIGLU && t1 < 0.90 * best) { best = t1; cfg = 1; }   // the small tile loses on long k-loops at equal estimate
     }
     if (d.M < 256 && cfg >= 2 && cfg != 4) cfg = 4;
-    if (force >= 0) cfg = force;
+    if (force >= 0 && force <= 4) cfg = force;
+    // EP_ROWSTATS reduces a row over the 16 lanes that hold one 64-column group: the 32-column-wide 256x32 tile has no such group
+    if ((d.flags & ADA_EP_ROWSTATS) && cfg == 0) cfg = 1;
     if constexpr (EPI == EPI_SWIGLU) {
         if (cfg == 4 || cfg == 2) return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
-        if (cfg == 5) return launch_cfg<128, 256, 32, 2, 2, EPI>(d, s);
         if (d.variant >= 8) return launch_cfg<256, 256, 64, 2, 4, EPI, 1>(d, s);
         return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
     } else if constexpr (EPI == EPI_TAIL) {
@@ -1122,8 +1124,6 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
             case 1: return launch_cfg<128, 64, 64, 4, 1, EPI>(d, s);
             case 2: return launch_cfg<256, 128, 64, 4, 2, EPI>(d, s);
             case 4: return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
-            case 5: return launch_cfg<128, 256, 32, 2, 2, EPI>(d, s);
-            case 7: return launch_cfg<512, 128, 64, 8, 1, EPI>(d, s);
             default:
                 if (d.variant >= 8) return launch_cfg<256, 256, 64, 2, 4, EPI, 1>(d, s);
                 return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
@@ -1133,17 +1133,18 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force, int short_k_cfg) {
 
 }  // namespace
 
-// ---- tuning / diagnostic hooks (declared in include/ada_hip.h; process-global, not needed for correct operation) ----
-static unsigned long long* g_dbg = nullptr;
-static int g_force_tile = -1, g_short_k_cfg = 3, g_variant = 4;   // 0/1/2/4: single-barrier main loop with its copy-stagger flavours (4 = default); 8: phased ping-pong main loop for the 256x256 tile
-static bool g_env_read = false;
+// ---- tuning / diagnostic hooks (declared in include/ada_hip.h; process-global atomics, not needed for correct operation) ----
+static std::atomic<unsigned long long*> g_dbg{nullptr};
+static std::atomic<int> g_force_tile{-1};
+static std::atomic<int> g_variant{4};   // 4: single-barrier main loop (default); 8: phased ping-pong main loop for the 256x256 tile
+static std::once_flag g_env_once;
 // debug hook (not part of the stable ABI): override the tile configuration (-1 = heuristic)
-extern "C" void ada_debug_set_tile(int cfg) { g_force_tile = cfg; g_env_read = true; }
-extern "C" void ada_debug_set_variant(int v) { g_variant = v; }
-extern "C" void ada_debug_set_group(int g) { g_group_override = g; }
+extern "C" void ada_debug_set_tile(int cfg) { g_force_tile.store(cfg, std::memory_order_relaxed); }
+extern "C" void ada_debug_set_variant(int v) { g_variant.store(v >= 8 ? 8 : 4, std::memory_order_relaxed); }
+extern "C" void ada_debug_set_group(int g) { g_group_override.store(g, std::memory_order_relaxed); }
 extern "C" int ada_debug_last_tile(void) { return g_last_tile; }
 // debug hook (not part of the stable ABI): device buffer of 8 x u64 per workgroup, or NULL to disable
-extern "C" void ada_debug_set_timestamps(void* dev_buf) { g_dbg = (unsigned long long*)dev_buf; }
+extern "C" void ada_debug_set_timestamps(void* dev_buf) { g_dbg.store((unsigned long long*)dev_buf, std::memory_order_relaxed); }
 
 extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     ADA_REQUIRE(a != nullptr, ADA_EINVAL, "ada_igemm: null args");
@@ -1248,25 +1249,19 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.group_n = 1;
     d.tiles_m = d.tiles_n = 0;
 
-    // A/B switches for kernel experiments (read once): tile override, main-loop schedule, tile used for short k-loops
-    if (!g_env_read) {
-        g_env_read = true;
-        const char* e = getenv("ADA_IGEMM_TILE");
-        g_force_tile = e ? atoi(e) : -1;
-        const char* gr = getenv("ADA_IGEMM_GROUP");
-        if (gr) g_group_override = atoi(gr);
-        const char* va = getenv("ADA_IGEMM_VARIANT");
-        if (va) g_variant = atoi(va);
-        const char* sk = getenv("ADA_IGEMM_SHORTK");
-        g_short_k_cfg = sk ? atoi(sk) : 3;
-    }
-    const int force = g_force_tile, short_k_cfg = g_short_k_cfg;
-    d.dbg = g_dbg;
-    d.variant = g_variant;
+    // A/B switches for kernel experiments: the environment presets the hooks above once per process
+    std::call_once(g_env_once, []() {
+        if (const char* e = getenv("ADA_IGEMM_TILE")) ada_debug_set_tile(atoi(e));
+        if (const char* gr = getenv("ADA_IGEMM_GROUP")) ada_debug_set_group(atoi(gr));
+        if (const char* va = getenv("ADA_IGEMM_VARIANT")) ada_debug_set_variant(atoi(va));
+    });
+    const int force = g_force_tile.load(std::memory_order_relaxed);
+    d.dbg = g_dbg.load(std::memory_order_relaxed);
+    d.variant = g_variant.load(std::memory_order_relaxed);
     hipStream_t s = (hipStream_t)stream;
-    if (tail) return launch_epi<EPI_TAIL>(d, s, a->N <= 32 ? 0 : 1, 3);
-    if (swiglu) return launch_epi<EPI_SWIGLU>(d, s, force, short_k_cfg);
-    if (shuffle) return launch_epi<EPI_SHUFFLE>(d, s, force, short_k_cfg);
-    if (f & ADA_EP_GELU) return launch_epi<EPI_GELU>(d, s, force, short_k_cfg);
-    return launch_epi<EPI_STD>(d, s, force, short_k_cfg);
+    if (tail) return launch_epi<EPI_TAIL>(d, s, a->N <= 32 ? 0 : 1);
+    if (swiglu) return launch_epi<EPI_SWIGLU>(d, s, force);
+    if (shuffle) return launch_epi<EPI_SHUFFLE>(d, s, force);
+    if (f & ADA_EP_GELU) return launch_epi<EPI_GELU>(d, s, force);
+    return launch_epi<EPI_STD>(d, s, force);
 }

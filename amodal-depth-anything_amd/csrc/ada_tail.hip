@@ -218,10 +218,14 @@ extern "C" int ada_dpt_tail_fwd(const float* in, int64_t ld_in, int32_t batch, i
     const size_t smem = (size_t)T_HALO_BYTES + T_W_BYTES + (size_t)npatch_max * 256;
     ADA_REQUIRE(smem <= 160 * 1024, ADA_EUNSUPPORTED, "ada_dpt_tail_fwd: source patch of %d x %d pixels does not fit in LDS (down-sampling is not supported)", ph_max, pw_max);
     p.pw_max = pw_max;
+#ifdef ADA_TAIL_ABLATION   // timing experiments only (csrc/build.py --tag abl -D ADA_TAIL_ABLATION): never in the shipped library
     {
         const char* e = getenv("ADA_TAIL_ABLATE");
         p.ablate = e ? atoi(e) : 0;
     }
+#else
+    p.ablate = 0;
+#endif
     static std::once_flag once;
     std::call_once(once, []() {
         if (hipFuncSetAttribute((const void*)dpt_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();

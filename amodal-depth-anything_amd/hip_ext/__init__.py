@@ -31,7 +31,7 @@ EXPORTS = (
     "ada_rowstats_finalize", "ada_pos_embed_resize", "ada_layernorm_fwd", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
     "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd", "ada_dpt_tail_fwd",
     "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
-    "ada_debug_set_timestamps", "ada_debug_set_attention_variant", "ada_debug_set_attention_profile",
+    "ada_debug_set_timestamps", "ada_debug_set_attention_variant",
 )
 
 # indices into the per-image sums of ada_depth_eval_fwd (ADA_EVAL_* in include/ada_hip.h)
@@ -125,7 +125,7 @@ def load(path: Optional[str] = None):
     for name in ("ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_set_attention_variant"):
         getattr(lib, name).argtypes = [c_int]
         getattr(lib, name).restype = None
-    for name in ("ada_debug_set_timestamps", "ada_debug_set_attention_profile"):
+    for name in ("ada_debug_set_timestamps",):
         getattr(lib, name).argtypes = [c_void_p]
         getattr(lib, name).restype = None
     lib.ada_debug_last_tile.argtypes = []
@@ -343,7 +343,7 @@ def depth_eval(pred, gt, mask=None, scale_shift=None, clip=None) -> torch.Tensor
 
 
 # --- tuning / diagnostic hooks (include/ada_hip.h, last section) ---------------------------------
-TILE_NAMES = {0: "256x32", 1: "128x64", 2: "256x128", 3: "256x256", 4: "128x128", 5: "128x256x32", 7: "512x128"}
+TILE_NAMES = {0: "256x32", 1: "128x64", 2: "256x128", 3: "256x256", 4: "128x128"}
 
 
 _tile_log = None

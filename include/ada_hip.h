@@ -288,25 +288,23 @@ int ada_tile_blend_fwd(const float* tiles, int32_t batch, int32_t n_tiles, int32
 int ada_selftest(void* scratch, int64_t scratch_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Tuning / diagnostic hooks.  Process-global switches used by the test-suite (to run every tile
+ * Tuning / diagnostic hooks.  Process-global switches (atomics) used by the test-suite (to run every tile
  * configuration and both main loops of ada_igemm against the same references), by tools/ (A/B
  * timing) and by bench.py (to report which kernel ran).  They never change results beyond fp32
- * summation order.  The environment variables ADA_IGEMM_TILE / _VARIANT / _GROUP / _SHORTK preset
- * the same switches once, at the first ada_igemm call.
+ * summation order.  The environment variables ADA_IGEMM_TILE / _VARIANT / _GROUP and ADA_ATTN_VARIANT preset
+ * the same switches once, at the first ada_igemm / ada_attention_fwd call.  One default and at most one alternate per
+ * kernel family are built; what was measured and removed is recorded in DESIGN.md section 8 and profiles/.
  *   ada_debug_set_tile(cfg)      force the ada_igemm tile: 0 256x32, 1 128x64, 2 256x128, 3 256x256,
- *                                4 128x128, 5 128x256x32, 7 512x128; -1 = heuristic (default)
- *   ada_debug_set_variant(v)     main loop of the 256x256 tile: 0/1/2/4 = single-barrier loop with its copy-stagger
- *                                flavours (4 = default); 8 = phased ping-pong loop (same speed under the power cap)
+ *                                4 128x128; -1 = heuristic (default)
+ *   ada_debug_set_variant(v)     main loop of the 256x256 tile: 4 = single-barrier loop (default);
+ *                                8 = phased ping-pong loop (same speed under the power cap)
  *   ada_debug_set_group(g)       force the column-group width of the tile order (0 = traffic model)
  *   ada_debug_last_tile()        tile code of the calling thread's most recent ada_igemm launch
  *                                (+100 when the phased main loop ran), -1 before the first launch
  *   ada_debug_set_timestamps(p)  device buffer of 8 x u64 per workgroup receiving s_memtime stamps
  *                                of the single-barrier loop, or NULL (default)
  *   ada_debug_set_attention_variant(v)  5 = 4-wave kernel with the softmax interleaved between its MFMAs (default),
- *                                0 = 8-wave ping-pong kernel with static priority,
- *                                1 = the same without s_setprio, 2 = the same with per-wave s_memtime
- *                                interval stamps written to the ada_debug_set_attention_profile buffer
- *                                (8 x u64 per wave), 3 = the 4-wave round-1 kernel
+ *                                3 = the 4-wave round-1 kernel (load, QK^T, softmax, PV in sequence)
  * ---------------------------------------------------------------------------------------- */
 void ada_debug_set_tile(int cfg);
 void ada_debug_set_variant(int v);
@@ -314,7 +312,6 @@ void ada_debug_set_group(int g);
 int ada_debug_last_tile(void);
 void ada_debug_set_timestamps(void* dev_buf);
 void ada_debug_set_attention_variant(int v);
-void ada_debug_set_attention_profile(void* dev_buf);
 
 #ifdef __cplusplus
 }

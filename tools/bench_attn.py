@@ -21,7 +21,7 @@ if os.environ.get("ZERO"):
     qkv.zero_()
 out = torch.empty(B * N, D, dtype=op, device="cuda")
 reps = int(os.environ.get("REPS", 10))
-H.debug_set_attention_variant(int(os.environ.get("VARIANT", 0)))
+H.debug_set_attention_variant(int(os.environ.get("VARIANT", 5)))
 for _ in range(2):
     H.attention(qkv, out, B, N, heads)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

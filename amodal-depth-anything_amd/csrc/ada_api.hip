@@ -84,7 +84,39 @@ __global__ __launch_bounds__(64) void selftest_kernel(unsigned* result) {
     if (fail) atomicOr(result, fail);
 }
 
+// counts operand-typed elements that sit at the saturation value of to_op (|x| >= 65504 for fp16; bf16 has fp32's range, so there
+// only +-inf / NaN count) -- one 8-byte-per-lane strided sweep, per-wave shuffle reduction, one atomic per wave
+__global__ __launch_bounds__(256) void count_saturated_kernel(const op_t* __restrict__ buf, long n, unsigned long long* __restrict__ count) {
+    unsigned c = 0;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            const opx4 v = *(const opx4*)(buf + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = __builtin_fabsf((float)v[e]);
+                c += !(a < ADA_OP_SATURATION);     // also counts NaN
+            }
+        } else {
+            for (long k = i; k < n; ++k) c += !(__builtin_fabsf((float)buf[k]) < ADA_OP_SATURATION);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
+}
+
 }  // namespace
+
+extern "C" int ada_debug_count_saturated(const void* buf, int64_t n, void* count, void* stream) {
+    ADA_REQUIRE(buf && count && n >= 0, ADA_EINVAL, "ada_debug_count_saturated: null pointer / negative size");
+    ADA_REQUIRE(((uintptr_t)buf % 8) == 0 && ((uintptr_t)count % 8) == 0, ADA_EINVAL, "ada_debug_count_saturated: buffers must be 8-byte aligned");
+    if (n == 0) return ADA_OK;
+    long blocks = (n + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(count_saturated_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const op_t*)buf, (long)n,
+                       (unsigned long long*)count);
+    return ada_check_launch("ada_debug_count_saturated");
+}
 
 extern "C" int ada_selftest(void* scratch, int64_t scratch_bytes, void* stream) {
     ADA_REQUIRE(scratch && scratch_bytes >= 4, ADA_EINVAL, "ada_selftest: need >= 4 bytes of device scratch");

@@ -9,9 +9,11 @@
 #ifdef ADA_OPERAND_BF16
 typedef __bf16 op_t;
 #define ADA_OP_DTYPE ADA_DT_BF16
+#define ADA_OP_SATURATION 3.0e38f   /* bf16 conversions do not saturate: only inf / NaN register */
 #else
 typedef _Float16 op_t;
 #define ADA_OP_DTYPE ADA_DT_F16
+#define ADA_OP_SATURATION 65504.0f  /* to_op clamps to the largest finite fp16 */
 #endif
 
 typedef __attribute__((ext_vector_type(8))) op_t opx8;

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
 # --- constants mirrored from include/ada_hip.h ------------------------------------------------
-ABI_VERSION = 3
+ABI_VERSION = 4
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 A_PLAIN, A_CONV3 = 0, 1
 MAP_PLAIN, MAP_PAD, MAP_TOKEN, MAP_SHUFFLE = 0, 1, 2, 3
@@ -31,7 +31,7 @@ EXPORTS = (
     "ada_rowstats_finalize", "ada_pos_embed_resize", "ada_layernorm_fwd", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
     "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd", "ada_dpt_tail_fwd",
     "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
-    "ada_debug_set_timestamps", "ada_debug_set_attention_variant",
+    "ada_debug_set_timestamps", "ada_debug_set_attention_variant", "ada_debug_count_saturated",
 )
 
 # indices into the per-image sums of ada_depth_eval_fwd (ADA_EVAL_* in include/ada_hip.h)
@@ -128,6 +128,8 @@ def load(path: Optional[str] = None):
     for name in ("ada_debug_set_timestamps",):
         getattr(lib, name).argtypes = [c_void_p]
         getattr(lib, name).restype = None
+    lib.ada_debug_count_saturated.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
+    lib.ada_debug_count_saturated.restype = c_int
     lib.ada_debug_last_tile.argtypes = []
     lib.ada_debug_last_tile.restype = c_int
     if lib.ada_abi_version() != ABI_VERSION:
@@ -393,6 +395,15 @@ def debug_last_tile() -> int:
 def debug_set_attention_variant(v: int = 5):
     _bump_epoch()
     load().ada_debug_set_attention_variant(int(v))
+
+
+def count_saturated(buf: torch.Tensor, counter: torch.Tensor):
+    """Adds to ``counter`` (int64 [1] on the device) the number of elements of the operand-typed tensor ``buf`` that sit at the fp16 clamp
+    (+-65504) or are inf / NaN (ada_debug_count_saturated)."""
+    if not buf.is_contiguous():
+        raise HipExtError("count_saturated: contiguous tensor required")
+    _check(load().ada_debug_count_saturated(_dev(buf, "buf", operand_dtype()), buf.numel(), _dev(counter, "counter", torch.int64), _stream()),
+           "ada_debug_count_saturated")
 
 
 def selftest() -> int:

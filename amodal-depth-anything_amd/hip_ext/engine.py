@@ -29,18 +29,39 @@ import torch.nn.functional as F
 from . import (A_CONV3, ACT_NONE, ACT_RELU, ACT_SIGMOID, EP_BIAS, EP_GAMMA, EP_GELU, EP_LNFOLD, EP_RELU_OP, EP_RESIDUAL,
                EP_ROWSTATS, EP_SWIGLU, EP_TAIL, MAP_PAD, MAP_SHUFFLE, MAP_TOKEN, HipExtError)
 from . import attention as k_attention
-from . import bilinear as k_bilinear
+from . import bilinear as _bilinear
+from . import count_saturated
 from . import dpt_tail as k_dpt_tail
-from . import igemm as k_igemm
-from . import layernorm as k_layernorm
+from . import igemm as _igemm
+from . import layernorm as _layernorm
 from . import debug_epoch, instrumented, operand_dtype
 from . import patchify as k_patchify
 from . import pos_embed_resize as k_pos_embed_resize
 from . import rowstats_finalize as k_rowstats_finalize
 from . import write_cls as k_write_cls
 
+_probe = None   # list of (label, device counter) while DepthEngine.saturation_report runs, else None
+
+
+def _probed(kernel, launch):
+    """Wraps a launcher: while a saturation probe is active, the operand-typed output of every launch is swept by ada_debug_count_saturated."""
+    def run(*a, **kw):
+        launch(*a, **kw)
+        t = kw.get("out_op")
+        if _probe is not None and t is not None and t.is_contiguous():
+            c = torch.zeros(1, dtype=torch.int64, device=t.device)
+            count_saturated(t, c)
+            _probe.append((f"{kernel} #{len(_probe)} {list(t.shape)}", c))
+    return run
+
+
+k_igemm, k_layernorm, k_bilinear = _probed("igemm", _igemm), _probed("layernorm", _layernorm), _probed("bilinear", _bilinear)
+
 PATCH = 14
 LN_EPS = 1e-6
+# layer groups of the DPT head whose contractions can run in split precision (PackedWeights.split): "tok" = read-out / projects / resize_layers,
+# "ip" = input_projection convs, "rn" = layerN_rn, "rcu" = the ResidualConvUnit convs, "out" = the 1x1 out_convs, "oc1" / "oc2" = the tail convs
+HEAD_GROUPS = ("tok", "ip", "rn", "rcu", "out", "oc1", "oc2")
 # ada_dpt_tail_fwd (resize + output_conv2 fused, the up-sampled map never materialised) is built and parity-tested but OFF by default:
 # at ViT-L bs=32 it takes 2.69 ms against 2.18 ms for the resize kernel + tail GEMM it replaces -- with 123 KB of LDS only one 4-wave
 # workgroup fits a CU, so its interpolation phase runs at one wave per SIMD (1.18 ms) and 35 k short-lived workgroups pay their
@@ -65,7 +86,7 @@ class PackedWeights:
     """Operand-typed copies of the parameters, laid out for the kernels.  ``sd``: name -> fp32 CUDA tensor
     with the *raw* model's key names (``pretrained.*``, ``depth_head.*``)."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], encoder: str, guided: bool, amodal_head: bool, split_head: bool = False,
+    def __init__(self, sd: Dict[str, torch.Tensor], encoder: str, guided: bool, amodal_head: bool, split_head=False,
                  fold_ln: bool = False):
         op = operand_dtype()
         cfg = VIT[encoder]
@@ -75,7 +96,15 @@ class PackedWeights:
         # column segments by the producing kernel (split_seg) and weights are packed [w_hi | w_hi | w_lo], so one fp16 GEMM over
         # 3x the K evaluates x_hi w_hi + x_lo w_hi + x_hi w_lo (~fp32 operand accuracy).  Used where the head's operand rounding
         # is what limits parity: the unbounded-output models (raw ReLU / 'ssi' heads) and ViT-S.
-        self.split_head = split_head
+        # The choice is PER LAYER GROUP (HEAD_GROUPS): a contraction of a split group reads a [hi | lo | hi] activation (its producer is
+        # told through split_seg) and [w_hi | w_hi | w_lo] weights; the others run at 1x the MACs.  True = every group.
+        if split_head is True:
+            split_head = HEAD_GROUPS
+        self.split = frozenset(split_head or ())
+        unknown = self.split - set(HEAD_GROUPS)
+        if unknown:
+            raise HipExtError(f"unknown head layer group(s) {sorted(unknown)}; known: {HEAD_GROUPS}")
+        self.split_head = bool(self.split)
         # fold_ln: the block LayerNorms (reference block.py:84,87) are folded into the qkv / fc1 contractions that consume them --
         # gain into the weights, mean / rstd applied in the GEMM epilogue (ADA_EP_LNFOLD), row statistics produced by the proj / fc2
         # epilogue that writes the residual stream (ADA_EP_ROWSTATS): no stand-alone LayerNorm launch between the GEMMs of a block
@@ -169,25 +198,35 @@ class PackedWeights:
             self.blocks.append(blk)
         self.norm_w, self.norm_b = f32(p + "norm.weight"), f32(p + "norm.bias")
 
-        if split_head:   # from here on only head weights are packed
-            def triple(w2d):   # [..., K] fp32, K already padded to a multiple of 64
-                hi = w2d.to(op)
-                lo = (w2d - hi.float()).to(op)
-                return torch.cat([hi, hi, lo], dim=-1)
+        lin1, conv3_1 = lin, conv3
 
-            def lin(w):  # noqa: F811
-                w = w.reshape(w.shape[0], -1)
-                k = w.shape[1]
-                if k % 64:
-                    w = F.pad(w, (0, _r64(k) - k))
-                return triple(w).contiguous()
+        def triple(w2d):   # [..., K] fp32, K already padded to a multiple of 64
+            hi = w2d.to(op)
+            lo = (w2d - hi.float()).to(op)
+            return torch.cat([hi, hi, lo], dim=-1)
 
-            def conv3(w):  # noqa: F811  [Co, Ci, 3, 3] -> [Co, 9 * 3 * Cip]: per tap [hi | hi | lo]
-                co, ci = w.shape[:2]
-                w = w.permute(0, 2, 3, 1)
-                if ci % 64:
-                    w = F.pad(w, (0, _r64(ci) - ci))
-                return triple(w).reshape(co, -1).contiguous()
+        def lin(w, group):  # noqa: F811
+            if group not in self.split:
+                return lin1(w)
+            w = w.reshape(w.shape[0], -1)
+            k = w.shape[1]
+            if k % 64:
+                w = F.pad(w, (0, _r64(k) - k))
+            return triple(w).contiguous()
+
+        def conv3(w, group):  # noqa: F811  [Co, Ci, 3, 3] -> [Co, 9 * 3 * Cip]: per tap [hi | hi | lo]
+            if group not in self.split:
+                return conv3_1(w)
+            co, ci = w.shape[:2]
+            w = w.permute(0, 2, 3, 1)
+            if ci % 64:
+                w = F.pad(w, (0, _r64(ci) - ci))
+            return triple(w).reshape(co, -1).contiguous()
+
+        def convT(w, b, s_, group):  # noqa: F811  [Ci, Co, s, s] -> [s*s*Co, Cip], bias expanded to [s*s*Co]
+            ci, co = w.shape[:2]
+            wt = w.permute(2, 3, 1, 0).reshape(s_ * s_ * co, ci)
+            return lin(wt, group), b.repeat(s_ * s_).contiguous()
 
         h = "depth_head."
         # use_clstoken read-out (reference DA2/dpt.py:110-117,164-167): Linear(2D -> D) on [patch token | class token] + GELU.  The class
@@ -198,27 +237,27 @@ class PackedWeights:
             self.ro_wx, self.ro_wc, self.ro_b = [], [], []
             for i in range(4):
                 wr = f32(f"{h}readout_projects.{i}.0.weight")
-                self.ro_wx.append(lin(wr[:, :D]))
-                self.ro_wc.append(lin(wr[:, D:]))
+                self.ro_wx.append(lin(wr[:, :D], "tok"))
+                self.ro_wc.append(lin(wr[:, D:], "tok"))
                 self.ro_b.append(f32(f"{h}readout_projects.{i}.0.bias"))
         self.oc = [sd[f"{h}projects.{i}.weight"].shape[0] for i in range(4)]
         self.features = sd[h + "scratch.layer1_rn.weight"].shape[0]
-        self.proj_w = [lin(f32(f"{h}projects.{i}.weight")) for i in range(4)]
+        self.proj_w = [lin(f32(f"{h}projects.{i}.weight"), "tok") for i in range(4)]
         self.proj_b = [f32(f"{h}projects.{i}.bias") for i in range(4)]
-        self.rs0_w, self.rs0_b = convT(f32(h + "resize_layers.0.weight"), f32(h + "resize_layers.0.bias"), 4)
-        self.rs1_w, self.rs1_b = convT(f32(h + "resize_layers.1.weight"), f32(h + "resize_layers.1.bias"), 2)
-        self.rs3_w, self.rs3_b = conv3(f32(h + "resize_layers.3.weight")), f32(h + "resize_layers.3.bias")
+        self.rs0_w, self.rs0_b = convT(f32(h + "resize_layers.0.weight"), f32(h + "resize_layers.0.bias"), 4, "tok")
+        self.rs1_w, self.rs1_b = convT(f32(h + "resize_layers.1.weight"), f32(h + "resize_layers.1.bias"), 2, "tok")
+        self.rs3_w, self.rs3_b = conv3(f32(h + "resize_layers.3.weight"), "tok"), f32(h + "resize_layers.3.bias")
         if amodal_head:
-            self.ip_w = [conv3(f32(f"{h}input_projection.{i}.0.weight")) for i in range(4)]
+            self.ip_w = [conv3(f32(f"{h}input_projection.{i}.0.weight"), "ip") for i in range(4)]
             self.ip_b = [f32(f"{h}input_projection.{i}.0.bias") for i in range(4)]
             self.ip_ln_w = [f32(f"{h}input_projection.{i}.1.weight") for i in range(4)]
             self.ip_ln_b = [f32(f"{h}input_projection.{i}.1.bias") for i in range(4)]
         s = h + "scratch."
-        self.rn_w = [conv3(f32(f"{s}layer{i + 1}_rn.weight")) for i in range(4)]
+        self.rn_w = [conv3(f32(f"{s}layer{i + 1}_rn.weight"), "rn") for i in range(4)]
         self.fuse = []
         for k in range(1, 5):
             r = f"{s}refinenet{k}."
-            d = dict(out_w=lin(f32(r + "out_conv.weight")), out_b=f32(r + "out_conv.bias"))
+            d = dict(out_w=lin(f32(r + "out_conv.weight"), "out"), out_b=f32(r + "out_conv.bias"))
             for u in (1, 2):
                 for c in (1, 2):
                     w, b = f32(f"{r}resConfUnit{u}.conv{c}.weight"), f32(f"{r}resConfUnit{u}.conv{c}.bias")
@@ -226,11 +265,11 @@ class PackedWeights:
                     if bn + "running_var" in sd:      # use_bn=True: inference BatchNorm folded into the conv (reference blocks.py:70-76)
                         from .functional import fold_batchnorm
                         w, b = fold_batchnorm(w, b, f32(bn + "weight"), f32(bn + "bias"), f32(bn + "running_mean"), f32(bn + "running_var"))
-                    d[f"u{u}c{c}_w"] = conv3(w)
+                    d[f"u{u}c{c}_w"] = conv3(w, "rcu")
                     d[f"u{u}c{c}_b"] = b.contiguous()
             self.fuse.append(d)  # index k-1
-        self.oc1_w, self.oc1_b = conv3(f32(s + "output_conv1.weight")), f32(s + "output_conv1.bias")
-        self.oc2_w, self.oc2_b = conv3(f32(s + "output_conv2.0.weight")), f32(s + "output_conv2.0.bias")
+        self.oc1_w, self.oc1_b = conv3(f32(s + "output_conv1.weight"), "oc1"), f32(s + "output_conv1.bias")
+        self.oc2_w, self.oc2_b = conv3(f32(s + "output_conv2.0.weight"), "oc2"), f32(s + "output_conv2.0.bias")
         self.tail_w = f32(s + "output_conv2.2.weight").reshape(-1).contiguous()
         self.tail_b = float(f32(s + "output_conv2.2.bias").reshape(-1)[0].item())
 
@@ -268,7 +307,10 @@ class Workspace:
         T, P = B * N, B * Np
         Fch = pw_.features
         Fp = _r64(Fch)
-        m = 3 if pw_.split_head else 1     # split-precision head: op-typed head tensors hold [hi | lo | hi] segments
+        def mm(group):     # an op-typed head tensor holds [hi | lo | hi] segments iff the contraction that READS it is in a split group
+            return 3 if group in pw_.split else 1
+        m = mm("tok")
+        first = "ip" if pw_.amodal_head else "rn"     # the contraction that reads the reassembled maps L[i]
 
         def z(*shape, dtype=op):
             return torch.zeros(*shape, dtype=dtype, device=device)
@@ -296,28 +338,28 @@ class Workspace:
         self.t0 = z(P, m * ocp[0])
         self.t1 = z(P, m * ocp[1])
         self.pre3 = z(B, ph + 2, pw + 2, m * ocp[3])
-        self.L = [z(B, g[0] + 2, g[1] + 2, m * ocp[i]) for i, g in enumerate(self.grid)]
+        self.L = [z(B, g[0] + 2, g[1] + 2, mm(first) * ocp[i]) for i, g in enumerate(self.grid)]
         if pw_.amodal_head:
             self.ipf = [z(B * g[0] * g[1], oc[i], dtype=torch.float32) for i, g in enumerate(self.grid)]
-            self.L2 = [z(B, g[0] + 2, g[1] + 2, m * ocp[i]) for i, g in enumerate(self.grid)]
+            self.L2 = [z(B, g[0] + 2, g[1] + 2, mm("rn") * ocp[i]) for i, g in enumerate(self.grid)]
         self.rnx = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
-        self.rnr = [z(B, g[0] + 2, g[1] + 2, m * Fp) for g in self.grid]
-        self.tmpa = [z(B, g[0] + 2, g[1] + 2, m * Fp) for g in self.grid]
+        self.rnr = [z(B, g[0] + 2, g[1] + 2, mm("rcu") * Fp) for g in self.grid]
+        self.tmpa = [z(B, g[0] + 2, g[1] + 2, mm("rcu") * Fp) for g in self.grid]
         self.r = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
         self.s = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
-        self.sr = [z(B, g[0] + 2, g[1] + 2, m * Fp) for g in self.grid]
-        self.u = [z(B * g[0] * g[1], m * Fp) for g in self.grid]
+        self.sr = [z(B, g[0] + 2, g[1] + 2, mm("rcu") * Fp) for g in self.grid]
+        self.u = [z(B * g[0] * g[1], mm("out") * Fp) for g in self.grid]
         self.zf = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
         g0 = self.grid[0]
         self.g296 = (2 * g0[0], 2 * g0[1])
-        self.p1 = z(B, self.g296[0] + 2, self.g296[1] + 2, m * Fp)
+        self.p1 = z(B, self.g296[0] + 2, self.g296[1] + 2, mm("oc1") * Fp)
         half = Fch // 2
         self.half, self.halfp = half, _r64(half)
         self.oc1 = z(B * self.g296[0] * self.g296[1], half, dtype=torch.float32)
         # fused tail (ada_dpt_tail_fwd): resize + output_conv2 in one kernel, the up-sampled map is never materialised.  Needs the
         # single-precision head and a channel count that is already a multiple of 64 (ViT-B / ViT-L heads)
-        self.fused_tail = (not pw_.split_head) and half == self.halfp and FUSED_TAIL
-        self.fin = None if self.fused_tail else z(B, H + 2, W + 2, m * self.halfp)
+        self.fused_tail = ("oc2" not in pw_.split) and half == self.halfp and FUSED_TAIL
+        self.fin = None if self.fused_tail else z(B, H + 2, W + 2, mm("oc2") * self.halfp)
 
 
 GRAPH_MODE = os.environ.get("ADA_GRAPH", "auto")
@@ -391,6 +433,21 @@ class DepthEngine:
         else:
             self._ws.move_to_end(key)
         return ws
+
+    def saturation_report(self, x: torch.Tensor, guide: Optional[torch.Tensor]):
+        """Diagnostic forward, not the hot path: runs ``_forward`` with a probe behind every launch that writes an operand-typed tensor and
+        returns ``(output, report)``; ``report`` maps "<kernel> #<launch index> [rows x cols]" to the number of elements that sit at the fp16
+        clamp (+-65504: to_op saturates instead of overflowing to inf) or are non-finite.  An empty report = nothing saturated.  Meant for
+        real checkpoints with massive activations (the synthetic fills never get near the clamp)."""
+        global _probe
+        _probe = []
+        try:
+            out = self._forward(x, guide)
+            torch.cuda.synchronize(x.device)
+            rep = {label: int(c.item()) for label, c in _probe if int(c.item())}
+        finally:
+            _probe = None
+        return out, rep
 
     # ---- small helpers over igemm ---------------------------------------------------------
     @staticmethod
@@ -507,11 +564,11 @@ class DepthEngine:
             if i in taps:  # shared final LayerNorm on the tap, cls row dropped (dinov2.py:337-340)
                 tap = ws.taps[taps.index(i)]
                 k_layernorm(ws.x, D, P, D, w.norm_w, w.norm_b, LN_EPS, group_in=N, skip=1, out_op=tap, ld_op=tap.shape[1],
-                            split_seg=D if w.split_head else 0)
+                            split_seg=D if "tok" in w.split else 0)
                 if w.readout:   # the class token of every image (row b * N of the token matrix): input row stride N * D
                     j = taps.index(i)
                     k_layernorm(ws.x, N * D, B, D, w.norm_w, w.norm_b, LN_EPS, out_op=ws.cls_op[j], ld_op=ws.cls_op[j].shape[1],
-                                split_seg=D if w.split_head else 0)
+                                split_seg=D if "tok" in w.split else 0)
 
         return self._head(ws, B)
 
@@ -525,11 +582,11 @@ class DepthEngine:
         grid = ws.grid
         rows = [B * g[0] * g[1] for g in grid]
 
-        sp = w.split_head
         ocp, Fp = ws.ocp, ws.Fp
+        first = "ip" if w.amodal_head else "rn"     # the group of the contraction that reads the reassembled maps
 
-        def S(seg):   # split_seg argument of a producer whose consumer reads [hi | lo | hi] segments of width seg
-            return seg if sp else 0
+        def S(group, seg):   # split_seg argument of a producer whose CONSUMER (a contraction of `group`) reads [hi | lo | hi] segments of width seg
+            return seg if group in w.split else 0
 
         taps_in = ws.taps
         if w.readout:   # x = GELU(W_x x + (W_cls cls_b + b))  per image (DA2/dpt.py:164-167)
@@ -539,22 +596,22 @@ class DepthEngine:
                 k_igemm(M=B, N=D, K=KDr, k_alg=D, A=ws.cls_op[i], lda=KDr, W=w.ro_wc[i], bias=w.ro_b[i], flags=EP_BIAS, out_f32=ws.cls_bias[i], ldo_f32=D)
                 for b in range(B):
                     k_igemm(M=Np, N=D, K=KDr, k_alg=D, A=ws.taps[i][b * Np:(b + 1) * Np], lda=KDr, W=w.ro_wx[i], bias=ws.cls_bias[i][b],
-                            flags=EP_BIAS | EP_GELU, out_op=ws.taps_ro[i][b * Np:(b + 1) * Np], ldo_op=ws.taps_ro[i].shape[1], split_seg=S(D))
+                            flags=EP_BIAS | EP_GELU, out_op=ws.taps_ro[i][b * Np:(b + 1) * Np], ldo_op=ws.taps_ro[i].shape[1], split_seg=S("tok", D))
             taps_in = ws.taps_ro
         # ---- reassemble: 1x1 project + resize (dpt.py:171-173) -> zero-bordered NHWC operand tensors -----
         KD = ws.taps[0].shape[1]
-        k_igemm(M=P, N=oc[0], K=KD, k_alg=D, A=taps_in[0], lda=KD, W=w.proj_w[0], bias=w.proj_b[0], flags=EP_BIAS, out_op=ws.t0, ldo_op=ws.t0.shape[1], split_seg=S(ocp[0]))
+        k_igemm(M=P, N=oc[0], K=KD, k_alg=D, A=taps_in[0], lda=KD, W=w.proj_w[0], bias=w.proj_b[0], flags=EP_BIAS, out_op=ws.t0, ldo_op=ws.t0.shape[1], split_seg=S("tok", ocp[0]))
         k_igemm(M=P, N=16 * oc[0], K=ws.t0.shape[1], k_alg=oc[0], A=ws.t0, lda=ws.t0.shape[1], W=w.rs0_w, bias=w.rs0_b, flags=EP_BIAS,
-                out_op=ws.L[0], ldo_op=ws.L[0].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=4, shuffle_c=oc[0], split_seg=S(ocp[0]))
-        k_igemm(M=P, N=oc[1], K=KD, k_alg=D, A=taps_in[1], lda=KD, W=w.proj_w[1], bias=w.proj_b[1], flags=EP_BIAS, out_op=ws.t1, ldo_op=ws.t1.shape[1], split_seg=S(ocp[1]))
+                out_op=ws.L[0], ldo_op=ws.L[0].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=4, shuffle_c=oc[0], split_seg=S(first, ocp[0]))
+        k_igemm(M=P, N=oc[1], K=KD, k_alg=D, A=taps_in[1], lda=KD, W=w.proj_w[1], bias=w.proj_b[1], flags=EP_BIAS, out_op=ws.t1, ldo_op=ws.t1.shape[1], split_seg=S("tok", ocp[1]))
         k_igemm(M=P, N=4 * oc[1], K=ws.t1.shape[1], k_alg=oc[1], A=ws.t1, lda=ws.t1.shape[1], W=w.rs1_w, bias=w.rs1_b, flags=EP_BIAS,
-                out_op=ws.L[1], ldo_op=ws.L[1].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=2, shuffle_c=oc[1], split_seg=S(ocp[1]))
+                out_op=ws.L[1], ldo_op=ws.L[1].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=2, shuffle_c=oc[1], split_seg=S(first, ocp[1]))
         k_igemm(M=P, N=oc[2], K=KD, k_alg=D, A=taps_in[2], lda=KD, W=w.proj_w[2], bias=w.proj_b[2], flags=EP_BIAS,
-                out_op=ws.L[2], ldo_op=ws.L[2].shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S(ocp[2]))
+                out_op=ws.L[2], ldo_op=ws.L[2].shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S(first, ocp[2]))
         k_igemm(M=P, N=oc[3], K=KD, k_alg=D, A=taps_in[3], lda=KD, W=w.proj_w[3], bias=w.proj_b[3], flags=EP_BIAS,
-                out_op=ws.pre3, ldo_op=ws.pre3.shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S(ocp[3]))
+                out_op=ws.pre3, ldo_op=ws.pre3.shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S("tok", ocp[3]))
         self._conv3(ws.pre3, w.rs3_w, rows[3], oc[3], grid[3], stride=2, cin=oc[3], bias=w.rs3_b, flags=EP_BIAS,
-                    out_op=ws.L[3], ldo_op=ws.L[3].shape[3], map_op=MAP_PAD, map_h=grid[3][0], map_w=grid[3][1], split_seg=S(ocp[3]))
+                    out_op=ws.L[3], ldo_op=ws.L[3].shape[3], map_op=MAP_PAD, map_h=grid[3][0], map_w=grid[3][1], split_seg=S(first, ocp[3]))
 
         # ---- amodal only: input_projection = conv3x3 -> channels-first LN -> ReLU (dpt.py:153-159,178-179) ----
         layers = ws.L
@@ -562,19 +619,19 @@ class DepthEngine:
             for i in range(4):
                 self._conv3(ws.L[i], w.ip_w[i], rows[i], oc[i], grid[i], cin=oc[i], bias=w.ip_b[i], flags=EP_BIAS, out_f32=ws.ipf[i], ldo_f32=oc[i])
                 k_layernorm(ws.ipf[i], oc[i], rows[i], oc[i], w.ip_ln_w[i], w.ip_ln_b[i], LN_EPS, out_op=ws.L2[i],
-                            ld_op=ws.L2[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], relu=True, split_seg=S(ocp[i]))
+                            ld_op=ws.L2[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], relu=True, split_seg=S("rn", ocp[i]))
             layers = ws.L2
 
         # ---- layerN_rn (blocks.py:20-24): fp32 copy for the residual adds + ReLU'd operand copy for conv1 ----
         for i in range(4):
             self._conv3(layers[i], w.rn_w[i], rows[i], Fch, grid[i], cin=oc[i], flags=EP_RELU_OP, out_f32=ws.rnx[i], ldo_f32=Fch,
-                        out_op=ws.rnr[i], ldo_op=ws.rnr[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], split_seg=S(Fp))
+                        out_op=ws.rnr[i], ldo_op=ws.rnr[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], split_seg=S("rcu", Fp))
 
         def rcu(i, fw, unit, src_relu_pad, src_f32, **out):
             """ResidualConvUnit (blocks.py:57-80) at grid i: conv2(relu(conv1(relu(x)))) + x."""
             g = grid[i]
             self._conv3(src_relu_pad, fw[f"u{unit}c1_w"], rows[i], Fch, g, cin=Fch, bias=fw[f"u{unit}c1_b"], flags=EP_BIAS | EP_RELU_OP,
-                        out_op=ws.tmpa[i], ldo_op=ws.tmpa[i].shape[3], map_op=MAP_PAD, map_h=g[0], map_w=g[1], split_seg=S(Fp))
+                        out_op=ws.tmpa[i], ldo_op=ws.tmpa[i].shape[3], map_op=MAP_PAD, map_h=g[0], map_w=g[1], split_seg=S("rcu", Fp))
             self._conv3(ws.tmpa[i], fw[f"u{unit}c2_w"], rows[i], Fch, g, cin=Fch, bias=fw[f"u{unit}c2_b"], res=src_f32, ldr=Fch,
                         flags=EP_BIAS | EP_RESIDUAL, **out)
 
@@ -583,17 +640,17 @@ class DepthEngine:
         s_f32, s_pad = ws.rnx[3], ws.rnr[3]
         for i in (3, 2, 1, 0):
             fw = w.fuse[i]
-            rcu(i, fw, 2, s_pad, s_f32, out_op=ws.u[i], ldo_op=ws.u[i].shape[1], split_seg=S(Fp))
+            rcu(i, fw, 2, s_pad, s_f32, out_op=ws.u[i], ldo_op=ws.u[i].shape[1], split_seg=S("out", Fp))
             k_igemm(M=rows[i], N=Fch, K=ws.u[i].shape[1], k_alg=Fch, A=ws.u[i], lda=ws.u[i].shape[1], W=fw["out_w"], bias=fw["out_b"], flags=EP_BIAS,
                     out_f32=ws.zf[i], ldo_f32=Fch)
             if i > 0:
                 j = i - 1
                 rcu(j, w.fuse[j], 1, ws.rnr[j], ws.rnx[j], out_f32=ws.r[j], ldo_f32=Fch)
                 k_bilinear(ws.zf[i], Fch, B, grid[i][0], grid[i][1], grid[j][0], grid[j][1], Fch, add=ws.r[j], ld_add=Fch,
-                           out_f32=ws.s[j], ld_f32=Fch, out_op=ws.sr[j], ld_op=ws.sr[j].shape[3], map_op=MAP_PAD, relu=True, split_seg=S(Fp))
+                           out_f32=ws.s[j], ld_f32=Fch, out_op=ws.sr[j], ld_op=ws.sr[j].shape[3], map_op=MAP_PAD, relu=True, split_seg=S("rcu", Fp))
                 s_f32, s_pad = ws.s[j], ws.sr[j]
         g2 = ws.g296
-        k_bilinear(ws.zf[0], Fch, B, grid[0][0], grid[0][1], g2[0], g2[1], Fch, out_op=ws.p1, ld_op=ws.p1.shape[3], map_op=MAP_PAD, split_seg=S(Fp))
+        k_bilinear(ws.zf[0], Fch, B, grid[0][0], grid[0][1], g2[0], g2[1], Fch, out_op=ws.p1, ld_op=ws.p1.shape[3], map_op=MAP_PAD, split_seg=S("oc1", Fp))
 
         # ---- output_conv1 -> resize to (14 ph, 14 pw) -> output_conv2 (3x3, ReLU, 1x1, activation) (dpt.py:193-195) ----
         self._conv3(ws.p1, w.oc1_w, B * g2[0] * g2[1], ws.half, g2, cin=Fch, bias=w.oc1_b, flags=EP_BIAS, out_f32=ws.oc1, ldo_f32=ws.half)
@@ -601,7 +658,7 @@ class DepthEngine:
         if ws.fused_tail:
             k_dpt_tail(ws.oc1, ws.half, B, g2[0], g2[1], ws.H, ws.W, ws.halfp, w.oc2_w, w.oc2_b, w.tail_w, w.tail_b, self.final_act, out)
             return out
-        k_bilinear(ws.oc1, ws.half, B, g2[0], g2[1], ws.H, ws.W, ws.half, out_op=ws.fin, ld_op=ws.fin.shape[3], map_op=MAP_PAD, split_seg=S(ws.halfp))
+        k_bilinear(ws.oc1, ws.half, B, g2[0], g2[1], ws.H, ws.W, ws.half, out_op=ws.fin, ld_op=ws.fin.shape[3], map_op=MAP_PAD, split_seg=S("oc2", ws.halfp))
         self._conv3(ws.fin, w.oc2_w, B * ws.H * ws.W, w.oc2_w.shape[0], (ws.H, ws.W), cin=ws.half, bias=w.oc2_b, flags=EP_BIAS | EP_TAIL,
                     out_f32=out, ldo_f32=1, tail_w=w.tail_w, tail_b=w.tail_b, tail_act=self.final_act)
         return out

@@ -115,13 +115,31 @@ import os as _os
 _FOLD_LN_DEFAULT = _os.environ.get("ADA_FOLD_LN", "0") == "1"
 
 
+def _head_split_policy(mode, encoder, final_act):
+    """Which layer groups of the DPT head (hip_ext.engine.HEAD_GROUPS) run in split precision.  ``mode``: "auto" | "split" (all groups) |
+    "single" (none) | a comma-separated string / iterable of group names.  ADA_HEAD_SPLIT overrides "auto" (experiments)."""
+    from hip_ext.engine import HEAD_GROUPS
+    if mode == "auto" and _os.environ.get("ADA_HEAD_SPLIT") is not None:
+        mode = _os.environ["ADA_HEAD_SPLIT"]
+    if mode == "split":
+        return frozenset(HEAD_GROUPS)
+    if mode in ("single", "", "none"):
+        return frozenset()
+    if mode == "auto":
+        return frozenset(HEAD_GROUPS) if (final_act != "sigmoid" or encoder == "vits") else frozenset()
+    if isinstance(mode, str):
+        mode = [g for g in mode.split(",") if g]
+    return frozenset(mode)
+
+
 class _EngineMixin:
     """Lazily builds / refreshes the packed weights + launch plan whenever a parameter changes."""
 
     def _engine(self):
         from hip_ext.engine import DepthEngine, PackedWeights
         params = [(k, v) for k, v in self.state_dict(keep_vars=True).items()]
-        stamp = tuple((v.data_ptr(), v._version) for _, v in params) + (getattr(self, "head_precision", "auto"), getattr(self, "fold_layernorm", _FOLD_LN_DEFAULT))
+        hp = getattr(self, "head_precision", "auto")
+        stamp = tuple((v.data_ptr(), v._version) for _, v in params) + (hp if isinstance(hp, str) else tuple(sorted(hp)), getattr(self, "fold_layernorm", _FOLD_LN_DEFAULT))
         if getattr(self, "_engine_stamp", None) != stamp:
             sd = {k: v.detach() for k, v in params}
             # Head precision policy ("auto"): the DPT head runs in split precision (3x its MACs) where its fp16 operand rounding
@@ -129,7 +147,7 @@ class _EngineMixin:
             # compresses the logit noise) and ViT-S (64-feature head: few terms per output to average the rounding over).  The
             # sigmoid ViT-B/L models -- the benchmarked configurations -- keep the single-precision head.
             mode = getattr(self, "head_precision", "auto")
-            split = mode == "split" or (mode == "auto" and (self.depth_head.final_act != "sigmoid" or self.encoder == "vits"))
+            split = _head_split_policy(mode, self.encoder, self.depth_head.final_act)
             pw = PackedWeights(sd, self.encoder, guided=self.pretrained.has_guidance, amodal_head=hasattr(self.depth_head, "input_projection"),
                                split_head=split, fold_ln=bool(getattr(self, "fold_layernorm", _FOLD_LN_DEFAULT)))
             object.__setattr__(self, "_engine_obj", DepthEngine(pw, self.depth_head.final_act, bool(getattr(self, "normalise_input", False))))

@@ -36,9 +36,32 @@ def _is_norm_key(key: str) -> bool:
     return "input_projection" in key and parent == "1"
 
 
+# "heavy" fill: DINOv2-style outlier features.  Real DINOv2 checkpoints carry a handful of hidden dimensions whose residual-stream
+# magnitude is 1-2 orders above the rest ("massive activations"); the standard fill above has none (every activation is O(1)).  The heavy
+# variant multiplies the LayerScale gains (ls1 / ls2 .gamma) of OUTLIER_CHANNELS by OUTLIER_GAIN in the first third of the blocks -- the
+# residual stream then carries those channels at ~30-100x the typical magnitude through every later LayerNorm, attention and MLP -- and
+# the final-norm gain of the same channels by 4, so the head sees them too.
+OUTLIER_CHANNELS = (5, 77, 191, 300)
+OUTLIER_GAIN = 40.0
+
+
+def _apply_outliers_(key: str, v: torch.Tensor) -> torch.Tensor:
+    parts = key.split(".")
+    if parts[-1] == "gamma" and "blocks" in parts:
+        blk = int(parts[parts.index("blocks") + 1])
+        if blk < 4:
+            idx = [c for c in OUTLIER_CHANNELS if c < v.numel()]
+            v[idx] = v[idx] * OUTLIER_GAIN
+    elif key.endswith("pretrained.norm.weight"):
+        idx = [c for c in OUTLIER_CHANNELS if c < v.numel()]
+        v[idx] = v[idx] * 4.0
+    return v
+
+
 @torch.no_grad()
-def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int = 0) -> Dict[str, torch.Tensor]:
-    """Overwrites every floating tensor of ``sd`` in place; returns ``sd``."""
+def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int = 0, tail: str = "normal") -> Dict[str, torch.Tensor]:
+    """Overwrites every floating tensor of ``sd`` in place; returns ``sd``.  ``tail``: "normal" | "heavy" (outlier channels, see above)."""
+    assert tail in ("normal", "heavy"), tail
     for key, t in sd.items():
         if not torch.is_floating_point(t):
             continue
@@ -82,6 +105,8 @@ def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int = 0) -> Dict[str, to
             v = v * (gain / fan_in ** 0.5)
         else:  # biases
             v = 0.1 * randn(*shape)
+        if tail == "heavy":
+            v = _apply_outliers_(key, v)
         t.copy_(v.to(t.dtype))
     return sd
 

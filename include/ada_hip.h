@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADA_ABI_VERSION 3
+#define ADA_ABI_VERSION 4
 
 /* status codes */
 #define ADA_OK 0
@@ -312,6 +312,11 @@ void ada_debug_set_group(int g);
 int ada_debug_last_tile(void);
 void ada_debug_set_timestamps(void* dev_buf);
 void ada_debug_set_attention_variant(int v);
+/* Saturation probe.  fp32 -> operand conversions clamp to the largest finite fp16 (+-65504) instead of overflowing to inf
+ * (csrc/ada_common.h to_op); that is silent in the forward.  This adds, to the device counter *count (uint64, caller-zeroed), the
+ * number of elements of an operand-typed buffer of n elements that sit AT the clamp (or are inf / NaN), so a caller can sweep the
+ * activation buffers after a forward (hip_ext.engine.DepthEngine.saturation_report).  Asynchronous on `stream`; not on the hot path. */
+int ada_debug_count_saturated(const void* buf, int64_t n, void* count, void* stream);
 
 #ifdef __cplusplus
 }

@@ -38,20 +38,25 @@ def schema_key(case):
     return f"amodal/{case['encoder']}/{case['guide_type']}"
 
 
-def schema_state_dict(case, meta=None, seed=0):
+def _fill(sd, case, seed):
+    """The fill a fixture was generated with: case["weight_seed"] / case["tail"] unless a seed is forced."""
+    fill_state_dict_(sd, case.get("weight_seed", 0) if seed is None else seed, tail=case.get("tail", "normal"))
+
+
+def schema_state_dict(case, meta=None, seed=None):
     """Synthetic state_dict built from the reference's key/shape schema fixture (no nn.Module construction: fast)."""
     schema = json.load(open(os.path.join(GOLDEN_DIR, "state_dict_schema.json")))[schema_key(case)]
     sd = {k: torch.zeros(shape, dtype=torch.long if k.endswith("num_batches_tracked") else torch.float32) for k, shape in schema.items()}
-    fill_state_dict_(sd, seed)
+    _fill(sd, case, seed)
     if meta is not None:
         sd[meta["final_bias_key"]] = torch.full_like(sd[meta["final_bias_key"]], meta["final_bias"])
     return sd
 
 
-def synth_state_dict(model, meta=None, seed=0):
-    """fp32 CPU state_dict with the deterministic synthetic fill (+ the fixture's logit-centring bias)."""
+def synth_state_dict(model, meta=None, seed=None):
+    """fp32 CPU state_dict with the deterministic synthetic fill the fixture was generated with (+ its logit-centring bias)."""
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    fill_state_dict_(sd, seed)
+    _fill(sd, meta["case"] if meta is not None else {}, seed)
     if meta is not None:
         sd[meta["final_bias_key"]] = torch.full_like(sd[meta["final_bias_key"]], meta["final_bias"])
     return sd

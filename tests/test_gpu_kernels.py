@@ -835,3 +835,32 @@ def test_pos_embed_bicubic_resize_matches_aten(hip, ph, pw, dim):
     assert ref.shape[-2:] == (ph, pw)
     ref = torch.cat([pos[:1], ref.permute(0, 2, 3, 1).reshape(ph * pw, dim)], 0)
     _close(out, ref, 3e-6, rtol=1e-5, what="bicubic pos embed")
+
+
+def test_operand_store_saturates_and_is_counted(hip):
+    """fp32 -> fp16 operand stores clamp to +-65504 instead of overflowing to inf (csrc/ada_common.h to_op), and the saturation probe
+    (ada_debug_count_saturated) finds exactly the clamped elements.  bf16 builds have fp32's range: nothing clamps, nothing is counted."""
+    op = _op(hip)
+    M, N, K = 300, 128, 64
+    A = torch.ones(M, K).to(op).to(DEV)
+    W = torch.zeros(N, K)
+    W[:40] = 2000.0        # 64 * 2000 = 128000 > 65504
+    W[40:80] = -2000.0
+    W[80:] = 3.0
+    out = torch.zeros(M, N, dtype=op, device=DEV)
+    hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=W.to(op).to(DEV), flags=0, out_op=out, ldo_op=N)
+    counter = torch.zeros(1, dtype=torch.int64, device=DEV)
+    hip.count_saturated(out, counter)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all() or op == torch.bfloat16
+    assert torch.equal(got[:, 80:], torch.full((M, 48), 192.0))
+    if op == torch.float16:
+        assert torch.equal(got[:, :40], torch.full((M, 40), 65504.0)) and torch.equal(got[:, 40:80], torch.full((M, 40), -65504.0))
+        assert int(counter.item()) == M * 80
+    else:
+        assert int(counter.item()) == 0
+    # odd length / tail elements of the sweep
+    counter.zero_()
+    flat = out.reshape(-1)[: M * N - 3]
+    hip.count_saturated(flat, counter)
+    assert int(counter.item()) == (M * 80 if op == torch.float16 else 0)

@@ -303,6 +303,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_v3(const op_t* __rest
 //                  D   lgkmcnt(0), vmcnt(0), one barrier (copies of K(j+2), V(j+1) were issued at the top of the iteration)
 //   The order inside B / C is pinned group by group with sched_barrier(0): one MFMA, then its fillers.
 // =====================================================================================================================
+// Row sums of P on the matrix pipe (ADA_ATTN_MFMA_ROWSUM, round 3).  The kernel is VALU-issue bound with the matrix pipe ~40 % busy, so
+// the 32 fp32 adds per tile and wave that accumulated l = sum_k P are traded for 4 half-size MFMAs: each P fragment (the B operand of a
+// 32x32x16 PV step: lane l = query l&31, 8 k-slots of half l>>5) is ALSO a valid B operand of v_mfma_f32_16x16x32 -- there lane l means
+// column l&15, k-group l>>4, i.e. k-groups {0, 2} hold query n's 16 keys and {1, 3} those of query n + 16.  A constant A fragment whose
+// row 0 is 1 on k-groups {0, 2} and row 1 is 1 on {1, 3} makes D[0][n] = sum_k P[n][k], D[1][n] = sum_k P[n + 16][k]; the accumulator
+// carries the running l across tiles (C = D chain), is rescaled on the rare path, and is redistributed to the 64 lanes ONCE at the end.
+#ifndef ADA_ATTN_MFMA_ROWSUM
+#define ADA_ATTN_MFMA_ROWSUM 1
+#endif
 __global__ __launch_bounds__(256, 2) void attention_kernel_mix(const op_t* __restrict__ qkv, op_t* __restrict__ out,
                                                                int n_tok, int heads, int nqb, int n_bh) {
     __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE + 2 * V_TILE];   // [K0 | K1 | V0 | V1]
@@ -360,6 +369,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_mix(const op_t* __res
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.0f; o[1][r] = 0.0f; negm[r] = 0.0f; }
     float m_run = 0.0f, l_run = 0.0f;
     constexpr float RESCALE_THR = 8.0f;
+    constexpr bool MROW = ADA_ATTN_MFMA_ROWSUM != 0;
+    f32x4 lacc = {0.0f, 0.0f, 0.0f, 0.0f};     // MROW: rows 0 / 1 of the 16x16 row-sum tile (lanes 0-15: queries n and n + 16)
+    opx8 sel;                                  // MROW: the selector A fragment (row lane&15, k-group lane>>4)
+    {
+        const int srow_ = lane & 15, kg = lane >> 4;
+        const op_t one = (op_t)(((srow_ == 0 && (kg & 1) == 0) || (srow_ == 1 && (kg & 1) == 1)) ? 1.0f : 0.0f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sel[e] = one;
+    }
 
     const unsigned lds0 = (unsigned)(size_t)smem;
     const int swz = (l31 >> 1) & 7;
@@ -424,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_mix(const op_t* __res
         pp[1] = (op_t)e1;
         pn[kb][r >> 3][r & 7] = pp[0];
         pn[kb][r >> 3][(r & 7) + 1] = pp[1];
-        rs.add(e0, e1, pp, (r & 2) != 0);
+        if constexpr (!MROW) rs.add(e0, e1, pp, (r & 2) != 0);
     };
     auto fence = []() { __builtin_amdgcn_sched_barrier(0); };
 
@@ -491,7 +509,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_mix(const op_t* __res
                 const float delta = m_new - m_run;
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
                 const op_t alpha_op = (op_t)alpha;     // alpha <= 1; P(j-1) <= 2^8: no overflow
-                l_run *= alpha;
+                if constexpr (MROW) {   // row 0 of the row-sum tile belongs to this lane's query (lanes 0-15), row 1 to the query 16 lanes up
+                    lacc[0] *= alpha;
+                    lacc[1] *= __shfl(alpha, (lane & 15) + 16);
+                } else {
+                    l_run *= alpha;
+                }
                 m_run = m_new;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) negm[r] = -m_new;
@@ -517,6 +540,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_mix(const op_t* __res
             for (int g = 0; g < 8; ++g) {
                 const int kb = g >> 2, s = (g >> 1) & 1, db = g & 1;
                 o[db] = mfma32(vf[kb][s][db], pf[kb][s], o[db]);
+                if (MROW && db == 1) lacc = mfma16(sel, pf[kb][s], lacc);
                 if (g < 4) { sm_unit(2 * g); sm_unit(2 * g + 1); }
                 else sm_unit(4 + g);
                 if (g < 4) { read_k(PN{}, 0, g); read_k(PN{}, 1, g); }
@@ -541,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_mix(const op_t* __res
                 }
                 fence();
             }
-            l_run += rs.total();
+            if constexpr (!MROW) l_run += rs.total();
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -565,11 +589,18 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_mix(const op_t* __res
         for (int g = 0; g < 8; ++g) {
             const int kb = g >> 2, s = (g >> 1) & 1, db = g & 1;
             o[db] = mfma32(vf[kb][s][db], pf[kb][s], o[db]);
+            if (MROW && db == 1) lacc = mfma16(sel, pf[kb][s], lacc);
         }
     }
-    float l_lo, l_hi;
-    half_exchange(l_run, l_lo, l_hi);
-    const float inv = 1.0f / (l_lo + l_hi);
+    float inv;
+    if constexpr (MROW) {   // query l&31's sum sits in lane l&15: row 0 for queries 0-15, row 1 for 16-31
+        const float s0 = __shfl(lacc[0], lane & 15), s1 = __shfl(lacc[1], lane & 15);
+        inv = 1.0f / (((lane & 31) < 16) ? s0 : s1);
+    } else {
+        float l_lo, l_hi;
+        half_exchange(l_run, l_lo, l_hi);
+        inv = 1.0f / (l_lo + l_hi);
+    }
     if (q_row < n_tok) {
         op_t* orow = out + ((long)b * n_tok + q_row) * D + (long)h * HD;
 #pragma unroll

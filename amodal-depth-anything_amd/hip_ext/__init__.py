@@ -32,6 +32,7 @@ EXPORTS = (
     "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd", "ada_dpt_tail_fwd",
     "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
     "ada_debug_set_timestamps", "ada_debug_set_attention_variant", "ada_debug_count_saturated",
+    "ada_stream_create_cu_mask", "ada_stream_destroy",
 )
 
 # indices into the per-image sums of ada_depth_eval_fwd (ADA_EVAL_* in include/ada_hip.h)
@@ -130,6 +131,10 @@ def load(path: Optional[str] = None):
         getattr(lib, name).restype = None
     lib.ada_debug_count_saturated.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
     lib.ada_debug_count_saturated.restype = c_int
+    lib.ada_stream_create_cu_mask.argtypes = [ctypes.POINTER(ctypes.c_uint32), c_int32, ctypes.POINTER(c_void_p)]
+    lib.ada_stream_create_cu_mask.restype = c_int
+    lib.ada_stream_destroy.argtypes = [c_void_p]
+    lib.ada_stream_destroy.restype = c_int
     lib.ada_debug_last_tile.argtypes = []
     lib.ada_debug_last_tile.restype = c_int
     if lib.ada_abi_version() != ABI_VERSION:
@@ -404,6 +409,21 @@ def count_saturated(buf: torch.Tensor, counter: torch.Tensor):
         raise HipExtError("count_saturated: contiguous tensor required")
     _check(load().ada_debug_count_saturated(_dev(buf, "buf", operand_dtype()), buf.numel(), _dev(counter, "counter", torch.int64), _stream()),
            "ada_debug_count_saturated")
+
+
+def cu_mask_stream(mask_bits, n_cus: int = 256, device=None) -> "torch.cuda.ExternalStream":
+    """A stream whose kernels run only on the compute units i with ``mask_bits[i]`` true (ada_stream_create_cu_mask).  The handle lives
+    for the life of the process (a handful of streams per engine)."""
+    words = (n_cus + 31) // 32
+    arr = (ctypes.c_uint32 * words)()
+    for i in range(n_cus):
+        if mask_bits[i]:
+            arr[i // 32] |= 1 << (i % 32)
+    handle = c_void_p()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        _check(load().ada_stream_create_cu_mask(arr, words, ctypes.byref(handle)), "ada_stream_create_cu_mask")
+    return torch.cuda.ExternalStream(handle.value, device=dev)
 
 
 def selftest() -> int:

@@ -368,6 +368,12 @@ GRAPH_MODE = os.environ.get("ADA_GRAPH", "auto")
 GRAPH_AUTO_PIXELS = int(os.environ.get("ADA_GRAPH_AUTO_PIXELS", str(518 * 518)))
 # Bounds of the per-shape caches (LRU): a variable-resolution stream of single images must not grow device memory without limit.  A shape is
 # captured only on its SECOND sighting (a one-off resolution pays no extra warm-up forward, synchronise and empty_cache).
+# Dual pipeline (ADA_DUAL): batches of >= DUAL_MIN_BATCH images run as TWO half-batch pipelines on two streams restricted to complementary halves
+# of every XCD's compute units (ada_stream_create_cu_mask), their launches enqueued alternately block by block.  The two pipelines drift apart
+# by a few launches, so the HBM-bound launches of one (LayerNorm, resizes, the fp32-residual epilogues: no FLOPs, ~15 % of a step) run beside
+# MFMA-bound launches of the other instead of serialising with them.  "1" = CU-masked streams, "plain" = two ordinary streams, "0" = off.
+DUAL_MODE = os.environ.get("ADA_DUAL", "0")
+DUAL_MIN_BATCH = int(os.environ.get("ADA_DUAL_MIN_BATCH", "8"))
 MAX_GRAPHS = int(os.environ.get("ADA_GRAPH_CACHE", "4"))
 MAX_WORKSPACES = int(os.environ.get("ADA_WORKSPACE_CACHE", "6"))
 
@@ -377,20 +383,20 @@ class _GraphedForward:
     kernel launches over a pre-allocated workspace (no host synchronisation, no data-dependent control flow), so the capture is exact;
     inputs are copied into the graph's static buffers and the result is cloned out of its pool."""
 
-    def __init__(self, eng: "DepthEngine", x: torch.Tensor, guide: Optional[torch.Tensor]):
+    def __init__(self, eng: "DepthEngine", x: torch.Tensor, guide: Optional[torch.Tensor], norm: Optional[bool] = None):
         dev = x.device
         self.x = x.detach().contiguous().float().clone()
         self.guide = None if guide is None else guide.detach().contiguous().float().clone()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):   # warm-up outside the capture: workspace, position table, per-kernel function attributes
-            eng._forward(self.x, self.guide)
+            eng._forward(self.x, self.guide, norm)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         # thread-local capture mode: other host threads may keep using the device (a serving process) while this one captures
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.out = eng._forward(self.x, self.guide)
+            self.out = eng._forward(self.x, self.guide, norm)
         self.lock = threading.Lock()
 
     def __call__(self, x: torch.Tensor, guide: Optional[torch.Tensor]) -> torch.Tensor:
@@ -415,6 +421,7 @@ class DepthEngine:
         self._ws: "OrderedDict[tuple, Workspace]" = OrderedDict()
         self._graphs: "OrderedDict[tuple, object]" = OrderedDict()   # key -> _GraphedForward | False (capture refused) | int (sightings)
         self._lock = threading.Lock()
+        self._dual_streams: Dict[str, tuple] = {}
 
     def max_batch(self, H: int, W: int) -> int:
         if H * W > MAX_ROWS:
@@ -422,8 +429,8 @@ class DepthEngine:
                               "use hip_ext.tiling.tiled_amodal_forward / tiled_raw_forward")
         return max(1, MAX_ROWS // (H * W))
 
-    def workspace(self, B, H, W, device) -> Workspace:
-        key = (B, H, W, str(device))
+    def workspace(self, B, H, W, device, slot: int = 0) -> Workspace:
+        key = (B, H, W, str(device), slot)
         ws = self._ws.get(key)
         if ws is None:
             while len(self._ws) >= max(1, MAX_WORKSPACES):
@@ -456,18 +463,22 @@ class DepthEngine:
         k_igemm(M=M, N=N, K=9 * Cp, k_alg=9 * (cin or Cp), A=src_pad, lda=Cp, W=w, a_mode=A_CONV3,
                 conv=(grid[0], grid[1], Hp, Wp, stride), **kw)
 
-    def forward(self, x: torch.Tensor, guide: Optional[torch.Tensor]) -> torch.Tensor:
-        """One forward.  The smallest problems are bound by the host's launch rate (~230 launches per image): for those the launch
+    def forward(self, x: torch.Tensor, guide: Optional[torch.Tensor], normalise: Optional[bool] = None) -> torch.Tensor:
+        """One forward.  ``normalise`` overrides the engine's default for the fused ImageNet normalisation of the input (the
+        patchify kernel applies (x - mean) / std on the fly: callers holding a [0, 1] image need no separate normalise pass).  The smallest problems are bound by the host's launch rate (~230 launches per image): for those the launch
         sequence is captured once per input shape into a HIP graph and replayed, bit-identically (``ADA_GRAPH`` = auto | 1 | 0)."""
         if not x.is_cuda:
             raise HipExtError("DepthEngine.forward: input must live on a HIP device (no CPU fallback in the product path)")
+        norm = self.normalise_input if normalise is None else bool(normalise)
+        if DUAL_MODE != "0" and x.shape[0] >= DUAL_MIN_BATCH and not torch.cuda.is_current_stream_capturing():
+            return self._forward_dual(x, guide, norm)
         mode = GRAPH_MODE
         use = mode == "1" or (mode == "auto" and x.shape[0] * x.shape[-2] * x.shape[-1] <= GRAPH_AUTO_PIXELS)
         # replay bypasses the Python wrappers: with a KernelTimer or a tile log attached the launches must be issued one by one
         if not use or instrumented() or torch.cuda.is_current_stream_capturing():
-            return self._forward(x, guide)
+            return self._forward(x, guide, norm)
         # the kernel variant / tile override / fused-tail switch in force at capture time are baked into the graph
-        key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device), debug_epoch(), FUSED_TAIL)
+        key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device), debug_epoch(), FUSED_TAIL, norm)
         with self._lock:
             g = self._graphs.get(key)
             if g is not None:
@@ -479,7 +490,7 @@ class DepthEngine:
                     g = False
                 else:
                     try:
-                        g = _GraphedForward(self, x, guide)
+                        g = _GraphedForward(self, x, guide, norm)
                     except RuntimeError as e:   # capture refused (e.g. an enclosing capture in another mode): same kernels, launched one by one
                         import warnings
                         warnings.warn(f"HIP-graph capture of the forward failed ({e}); this shape runs as plain launches")
@@ -488,10 +499,63 @@ class DepthEngine:
                 while len(self._graphs) > max(1, MAX_GRAPHS):
                     self._graphs.popitem(last=False)
         if g is False:
-            return self._forward(x, guide)
+            return self._forward(x, guide, norm)
         return g(x, guide)
 
-    def _forward(self, x: torch.Tensor, guide: Optional[torch.Tensor]) -> torch.Tensor:
+    def _streams_for(self, device):
+        key = str(device)
+        st = self._dual_streams.get(key)
+        if st is None:
+            if DUAL_MODE == "plain":
+                st = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+            else:
+                from . import cu_mask_stream
+                n = torch.cuda.get_device_properties(device).multi_processor_count
+                low = [i < n // 2 for i in range(n)]      # consecutive mask bits go round-robin over the XCDs: half of EVERY XCD
+                st = (cu_mask_stream(low, n, device), cu_mask_stream([not b for b in low], n, device))
+            self._dual_streams[key] = st
+        return st
+
+    def _forward_dual(self, x: torch.Tensor, guide: Optional[torch.Tensor], norm: Optional[bool] = None) -> torch.Tensor:
+        """Two half-batch pipelines on complementary compute-unit sets (see DUAL_MODE); bit-identical to the single-stream forward
+        (the kernels are batch invariant)."""
+        B = x.shape[0]
+        half = (B + 1) // 2
+        dev = x.device
+        main = torch.cuda.current_stream(dev)
+        streams = self._streams_for(dev)
+        out = torch.empty(B, 1, x.shape[-2], x.shape[-1], dtype=torch.float32, device=dev)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        spans = ((0, half), (half, B))
+        gens = []
+        for slot, (s, (lo, hi)) in enumerate(zip(streams, spans)):
+            s.wait_event(ready)
+            gens.append(self._forward_steps(x[lo:hi], None if guide is None else guide[lo:hi], slot, norm))
+        live = [True, True]
+        while any(live):      # alternate the enqueues block by block: neither pipeline starts a whole forward's worth of launches late
+            for slot, (s, (lo, hi)) in enumerate(zip(streams, spans)):
+                if not live[slot]:
+                    continue
+                with torch.cuda.stream(s):
+                    res = next(gens[slot])
+                    if res is not None:
+                        out[lo:hi].copy_(res)
+                        live[slot] = False
+                        done = torch.cuda.Event()
+                        done.record(s)
+                        main.wait_event(done)
+        return out
+
+    def _forward(self, x: torch.Tensor, guide: Optional[torch.Tensor], norm: Optional[bool] = None) -> torch.Tensor:
+        for res in self._forward_steps(x, guide, 0, norm):
+            if res is not None:
+                return res
+        raise AssertionError("unreachable")
+
+    def _forward_steps(self, x: torch.Tensor, guide: Optional[torch.Tensor], slot: int, norm: Optional[bool] = None):
+        """The launch sequence as a generator: yields None after the token stage and after every transformer block (so two pipelines can be
+        enqueued alternately), and finally the output tensor."""
         w = self.w
         if not x.is_cuda:
             raise HipExtError("DepthEngine.forward: input must live on a HIP device (no CPU fallback in the product path)")
@@ -504,7 +568,7 @@ class DepthEngine:
                 raise HipExtError(f"guide tensor with {w.guide_channels} channels required")
             guide = guide.contiguous().float()
         x = x.contiguous().float()
-        ws = self.workspace(B, H, W, x.device)
+        ws = self.workspace(B, H, W, x.device, slot)
         D, heads = w.dim, w.heads
         ph, pw = ws.ph, ws.pw
         Np = ph * pw
@@ -512,13 +576,15 @@ class DepthEngine:
         T, P = B * N, B * Np
 
         # ---- tokens: patchify (+normalise) -> one GEMM over [rgb | guide] -> + bias + pos, cls row ----------
-        mean = (0.485, 0.456, 0.406) if self.normalise_input else None
-        inv_std = (1 / 0.229, 1 / 0.224, 1 / 0.225) if self.normalise_input else None
+        norm = self.normalise_input if norm is None else norm
+        mean = (0.485, 0.456, 0.406) if norm else None
+        inv_std = (1 / 0.229, 1 / 0.224, 1 / 0.225) if norm else None
         k_patchify(x, guide if w.guided else None, B, w.guide_channels, H, W, mean, inv_std, ws.a_pe, w.pe_k, split=True)
         pos = w.pos_embed(ph, pw)
         k_igemm(M=P, N=D, K=w.pe_k, k_alg=(3 + w.guide_channels) * 196, A=ws.a_pe, lda=w.pe_k, W=w.pe_w, bias=w.pe_b, res=pos, ldr=D, res_row_mod=Np, res_row_off=1,
                 flags=EP_BIAS | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, map_f32=MAP_TOKEN, map_h=Np)
         k_write_cls(ws.x, B, N, D, w.cls, pos)
+        yield None
 
         # ---- transformer blocks ------------------------------------------------------------------
         taps = TAPS[w.encoder]
@@ -569,8 +635,9 @@ class DepthEngine:
                     j = taps.index(i)
                     k_layernorm(ws.x, N * D, B, D, w.norm_w, w.norm_b, LN_EPS, out_op=ws.cls_op[j], ld_op=ws.cls_op[j].shape[1],
                                 split_seg=D if "tok" in w.split else 0)
+            yield None
 
-        return self._head(ws, B)
+        yield self._head(ws, B)
 
     def _head(self, ws: Workspace, B: int) -> torch.Tensor:
         w = self.w

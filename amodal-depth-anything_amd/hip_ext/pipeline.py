@@ -14,9 +14,6 @@ import torch
 
 from . import HipExtError, blend, minmax, normalize
 
-MEAN = (0.485, 0.456, 0.406)
-STD = (0.229, 0.224, 0.225)
-
 
 @torch.no_grad()
 def amodal_depth_pipeline(model_raw, amodal_model, rgb: torch.Tensor, mask01: torch.Tensor, rgb_raw: torch.Tensor = None):
@@ -26,10 +23,9 @@ def amodal_depth_pipeline(model_raw, amodal_model, rgb: torch.Tensor, mask01: to
     if not rgb.is_cuda:
         raise HipExtError("amodal_depth_pipeline: inputs must live on a HIP device")
     B, _, H, W = rgb.shape
-    mean = torch.tensor(MEAN, device=rgb.device).view(1, 3, 1, 1)
-    std = torch.tensor(STD, device=rgb.device).view(1, 3, 1, 1)
     src = rgb if rgb_raw is None else rgb_raw
-    base = model_raw(((src - mean) / std).contiguous()).contiguous()          # [B,H,W] >= 0   (caller-side normalise: infer.py:19)
+    # the caller-side ImageNet normalisation of infer.py:19 runs inside the raw model's patchify kernel (normalise_input): no extra pass
+    base = model_raw(src.contiguous(), normalise_input=True).contiguous()     # [B,H,W] >= 0
     mm = torch.empty(B, 2, dtype=torch.float32, device=rgb.device)
     minmax(base, mm)
     base_norm = torch.empty_like(base)

@@ -48,18 +48,24 @@ def tiled_apply(fn: Callable[..., torch.Tensor], inputs: Sequence[Optional[torch
     oys, oxs = tile_origins(H, tile, overlap), tile_origins(W, tile, overlap)
     origins: List[Tuple[int, int]] = [(y, x) for y in oys for x in oxs]
     T = len(origins)
-    tiles = torch.empty(B, T, tile, tile, dtype=torch.float32, device=first.device)
-    # crops of all images, tile-major inside an image; chunked so the batch handed to the network stays bounded
-    jobs = [(b, t) for b in range(B) for t in range(T)]
-    for i in range(0, len(jobs), max_tiles_per_call):
-        chunk = jobs[i:i + max_tiles_per_call]
-        crops = [None if inp is None else torch.stack([inp[b, :, origins[t][0]:origins[t][0] + tile, origins[t][1]:origins[t][1] + tile] for b, t in chunk]).contiguous()
+    dev = first.device
+    tiles = torch.empty(B * T, tile, tile, dtype=torch.float32, device=dev)
+    oy = torch.tensor([o[0] for o in origins], dtype=torch.int32, device=dev)
+    ox = torch.tensor([o[1] for o in origins], dtype=torch.int32, device=dev)
+    # crop (b, t) = job b * T + t.  Every chunk of jobs is cut out of each input by ONE gather (advanced indexing with broadcast
+    # row / column index tensors) and its predictions land in the tile stack by ONE copy: no per-tile device work is issued from Python.
+    ar = torch.arange(tile, device=dev)
+    rows = oy.long()[:, None] + ar          # [T, tile]
+    cols = ox.long()[:, None] + ar
+    jobs = torch.arange(B * T, device=dev)
+    for i in range(0, B * T, max_tiles_per_call):
+        j = jobs[i:i + max_tiles_per_call]
+        jb, jt = j // T, j % T
+        crops = [None if inp is None else
+                 inp[jb[:, None, None, None], torch.arange(inp.shape[1], device=dev)[None, :, None, None], rows[jt][:, None, :, None], cols[jt][:, None, None, :]]
                  for inp in inputs]
-        pred = fn(*crops).reshape(len(chunk), tile, tile).float()
-        for k, (b, t) in enumerate(chunk):
-            tiles[b, t] = pred[k]
-    oy = torch.tensor([o[0] for o in origins], dtype=torch.int32, device=first.device)
-    ox = torch.tensor([o[1] for o in origins], dtype=torch.int32, device=first.device)
+        tiles[i:i + j.numel()] = fn(*crops).reshape(j.numel(), tile, tile)
+    tiles = tiles.view(B, T, tile, tile)
     out = torch.empty(B, H, W, dtype=torch.float32, device=first.device)
     ramp = max(1, overlap)
     tile_blend(tiles, oy, ox, H, W, min(ramp, tile // 2), out)

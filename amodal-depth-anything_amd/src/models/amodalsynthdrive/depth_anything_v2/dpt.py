@@ -154,7 +154,7 @@ class _EngineMixin:
             object.__setattr__(self, "_engine_stamp", stamp)
         return self._engine_obj
 
-    def _run(self, x, guide):
+    def _run(self, x, guide, normalise=None):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # inference-only build: autograd through the HIP kernels is not provided (training is out of scope)
             pass
@@ -162,8 +162,8 @@ class _EngineMixin:
         B = x.shape[0]
         step = eng.max_batch(x.shape[-2], x.shape[-1])
         if B <= step:
-            return eng.forward(x, guide)
-        outs = [eng.forward(x[i:i + step], None if guide is None else guide[i:i + step]).clone() for i in range(0, B, step)]
+            return eng.forward(x, guide, normalise)
+        outs = [eng.forward(x[i:i + step], None if guide is None else guide[i:i + step], normalise).clone() for i in range(0, B, step)]
         return torch.cat(outs, dim=0)
 
 

@@ -27,8 +27,10 @@ class DepthAnythingV2(nn.Module, _EngineMixin):
         self.depth_head = DPTHead(self.pretrained.embed_dim, features, use_bn, out_channels=out_channels, use_clstoken=use_clstoken)
         self.normalise_input = False
 
-    def forward(self, x):
-        depth = self._run(x, None)   # tail ReLU of the head is fused; relu(relu(x)) == relu(x)
+    def forward(self, x, normalise_input=None):
+        """``x``: ImageNet-normalised image (reference RAW/dpt.py:176-184, infer.py:19).  ``normalise_input=True`` takes the [0, 1] image
+        instead and applies (x - mean) / std inside the patchify kernel (the on-device pipeline uses it: no separate normalise pass)."""
+        depth = self._run(x, None, normalise_input)   # tail ReLU of the head is fused; relu(relu(x)) == relu(x)
         return depth.squeeze(1)
 
     def forward_modular(self, x):

@@ -118,28 +118,6 @@ extern "C" int ada_debug_count_saturated(const void* buf, int64_t n, void* count
     return ada_check_launch("ada_debug_count_saturated");
 }
 
-// A HIP stream whose kernels are dispatched only to the compute units named in `mask` (bit i of word i / 32; the driver spreads consecutive
-// bits round-robin over the 8 XCDs, so "the low 128 bits" = CUs 0-15 of every XCD).  Used by the dual-pipeline forward
-// (hip_ext/engine.py): two half-batch pipelines on disjoint halves of every XCD, so the HBM-bound kernels of one overlap the MFMA-bound
-// kernels of the other.
-extern "C" int ada_stream_create_cu_mask(const uint32_t* mask, int32_t words, void** stream_out) {
-    ADA_REQUIRE(mask && stream_out && words > 0 && words <= 32, ADA_EINVAL, "ada_stream_create_cu_mask: bad arguments");
-    hipStream_t s = nullptr;
-    const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        ada_set_error("ada_stream_create_cu_mask: %s", hipGetErrorString(e));
-        return ADA_ELAUNCH;
-    }
-    *stream_out = (void*)s;
-    return ADA_OK;
-}
-extern "C" int ada_stream_destroy(void* stream) {
-    ADA_REQUIRE(stream != nullptr, ADA_EINVAL, "ada_stream_destroy: null stream");
-    if (hipStreamDestroy((hipStream_t)stream) != hipSuccess) return ada_check_launch("ada_stream_destroy");
-    return ADA_OK;
-}
-
 extern "C" int ada_selftest(void* scratch, int64_t scratch_bytes, void* stream) {
     ADA_REQUIRE(scratch && scratch_bytes >= 4, ADA_EINVAL, "ada_selftest: need >= 4 bytes of device scratch");
     hipStream_t s = (hipStream_t)stream;

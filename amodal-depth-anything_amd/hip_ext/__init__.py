@@ -32,7 +32,6 @@ EXPORTS = (
     "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd", "ada_dpt_tail_fwd",
     "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
     "ada_debug_set_timestamps", "ada_debug_set_attention_variant", "ada_debug_count_saturated",
-    "ada_stream_create_cu_mask", "ada_stream_destroy",
 )
 
 # indices into the per-image sums of ada_depth_eval_fwd (ADA_EVAL_* in include/ada_hip.h)
@@ -131,10 +130,6 @@ def load(path: Optional[str] = None):
         getattr(lib, name).restype = None
     lib.ada_debug_count_saturated.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
     lib.ada_debug_count_saturated.restype = c_int
-    lib.ada_stream_create_cu_mask.argtypes = [ctypes.POINTER(ctypes.c_uint32), c_int32, ctypes.POINTER(c_void_p)]
-    lib.ada_stream_create_cu_mask.restype = c_int
-    lib.ada_stream_destroy.argtypes = [c_void_p]
-    lib.ada_stream_destroy.restype = c_int
     lib.ada_debug_last_tile.argtypes = []
     lib.ada_debug_last_tile.restype = c_int
     if lib.ada_abi_version() != ABI_VERSION:
@@ -176,6 +171,7 @@ class KernelTimer:
 
     def __init__(self):
         self.records = {}
+        self.active = True     # bench.py brackets the launches of every 4th timed step only: the event records cost ~2 us of stream time each
 
     def start(self):
         ev = torch.cuda.Event(enable_timing=True)
@@ -229,7 +225,7 @@ def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=Non
     a.split_seg = split_seg
     a.ln_stats, a.ln_colsum = _opt(ln_stats, "ln_stats", torch.float32), _opt(ln_colsum, "ln_colsum", torch.float32)
     a.rowstat_out = _opt(rowstat_out, "rowstat_out", torch.float32)
-    if _timer is not None:
+    if _timer is not None and _timer.active:
         ev = _timer.start()
         _check(load().ada_igemm(ctypes.byref(a), _stream()), "ada_igemm")
         _timer.stop("igemm", ev, 2.0 * M * N * (k_alg if k_alg is not None else K))  # algorithmic FLOP (MAC = 2)
@@ -247,7 +243,7 @@ def rowstats_finalize(partials: torch.Tensor, rows: int, groups: int, eps: float
 
 def attention(qkv: torch.Tensor, out: torch.Tensor, batch: int, n_tokens: int, heads: int):
     op = operand_dtype()
-    ev = _timer.start() if _timer is not None else None
+    ev = _timer.start() if (_timer is not None and _timer.active) else None
     _check(load().ada_attention_fwd(_dev(qkv, "qkv", op), _dev(out, "out", op), batch, n_tokens, heads, _stream()),
            "ada_attention_fwd")
     if ev is not None:
@@ -296,7 +292,7 @@ def bilinear(inp, ld_in, batch, hi, wi, ho, wo, channels, *, add=None, ld_add=0,
 def dpt_tail(inp, ld_in, batch, hi, wi, ho, wo, cp, w, bias, tail_w, tail_b, tail_act, out):
     """Fused bilinear resize + output_conv2 (3x3 -> ReLU -> 1x1 -> activation), ada_dpt_tail_fwd."""
     op = operand_dtype()
-    ev = _timer.start() if _timer is not None else None
+    ev = _timer.start() if (_timer is not None and _timer.active) else None
     _check(load().ada_dpt_tail_fwd(_dev(inp, "in", torch.float32), ld_in, batch, hi, wi, ho, wo, cp, _dev(w, "w", op),
                                    _dev(bias, "bias", torch.float32), _dev(tail_w, "tail_w", torch.float32), tail_b, tail_act,
                                    _dev(out, "out", torch.float32), _stream()), "ada_dpt_tail_fwd")
@@ -409,21 +405,6 @@ def count_saturated(buf: torch.Tensor, counter: torch.Tensor):
         raise HipExtError("count_saturated: contiguous tensor required")
     _check(load().ada_debug_count_saturated(_dev(buf, "buf", operand_dtype()), buf.numel(), _dev(counter, "counter", torch.int64), _stream()),
            "ada_debug_count_saturated")
-
-
-def cu_mask_stream(mask_bits, n_cus: int = 256, device=None) -> "torch.cuda.ExternalStream":
-    """A stream whose kernels run only on the compute units i with ``mask_bits[i]`` true (ada_stream_create_cu_mask).  The handle lives
-    for the life of the process (a handful of streams per engine)."""
-    words = (n_cus + 31) // 32
-    arr = (ctypes.c_uint32 * words)()
-    for i in range(n_cus):
-        if mask_bits[i]:
-            arr[i // 32] |= 1 << (i % 32)
-    handle = c_void_p()
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    with torch.cuda.device(dev):
-        _check(load().ada_stream_create_cu_mask(arr, words, ctypes.byref(handle)), "ada_stream_create_cu_mask")
-    return torch.cuda.ExternalStream(handle.value, device=dev)
 
 
 def selftest() -> int:

@@ -59,9 +59,13 @@ k_igemm, k_layernorm, k_bilinear = _probed("igemm", _igemm), _probed("layernorm"
 
 PATCH = 14
 LN_EPS = 1e-6
-# layer groups of the DPT head whose contractions can run in split precision (PackedWeights.split): "tok" = read-out / projects / resize_layers,
-# "ip" = input_projection convs, "rn" = layerN_rn, "rcu" = the ResidualConvUnit convs, "out" = the 1x1 out_convs, "oc1" / "oc2" = the tail convs
-HEAD_GROUPS = ("tok", "ip", "rn", "rcu", "out", "oc1", "oc2")
+# Contractions of the DPT head that can run in split precision (PackedWeights.split), by name: "proj" = read-out + the four 1x1 `projects`,
+# "rs0" / "rs1" / "rs3" = resize_layers (ConvT 4x4, ConvT 2x2, conv3x3 stride 2), "ip<i>" = input_projection conv of level i,
+# "rn<i>" = layer<i+1>_rn, "rcu<i>" = the ResidualConvUnit convs of refinenet<i+1>, "out<i>" = its 1x1 out_conv, "oc1" / "oc2" = the tail
+# convs.  Level 0 is the finest grid (4x the patch grid), level 3 the coarsest.  HEAD_ALIASES name whole families.
+HEAD_GROUPS = ("proj", "rs0", "rs1", "rs3") + tuple(f"{f}{i}" for f in ("ip", "rn", "rcu", "out") for i in range(4)) + ("oc1", "oc2")
+HEAD_ALIASES = {"tok": ("proj", "rs0", "rs1", "rs3"), "ip": tuple(f"ip{i}" for i in range(4)), "rn": tuple(f"rn{i}" for i in range(4)),
+                "rcu": tuple(f"rcu{i}" for i in range(4)), "out": tuple(f"out{i}" for i in range(4))}
 # ada_dpt_tail_fwd (resize + output_conv2 fused, the up-sampled map never materialised) is built and parity-tested but OFF by default:
 # at ViT-L bs=32 it takes 2.69 ms against 2.18 ms for the resize kernel + tail GEMM it replaces -- with 123 KB of LDS only one 4-wave
 # workgroup fits a CU, so its interpolation phase runs at one wave per SIMD (1.18 ms) and 35 k short-lived workgroups pay their
@@ -100,7 +104,7 @@ class PackedWeights:
         # told through split_seg) and [w_hi | w_hi | w_lo] weights; the others run at 1x the MACs.  True = every group.
         if split_head is True:
             split_head = HEAD_GROUPS
-        self.split = frozenset(split_head or ())
+        self.split = frozenset(g for name in (split_head or ()) for g in HEAD_ALIASES.get(name, (name,)))
         unknown = self.split - set(HEAD_GROUPS)
         if unknown:
             raise HipExtError(f"unknown head layer group(s) {sorted(unknown)}; known: {HEAD_GROUPS}")
@@ -237,27 +241,27 @@ class PackedWeights:
             self.ro_wx, self.ro_wc, self.ro_b = [], [], []
             for i in range(4):
                 wr = f32(f"{h}readout_projects.{i}.0.weight")
-                self.ro_wx.append(lin(wr[:, :D], "tok"))
-                self.ro_wc.append(lin(wr[:, D:], "tok"))
+                self.ro_wx.append(lin(wr[:, :D], "proj"))
+                self.ro_wc.append(lin(wr[:, D:], "proj"))
                 self.ro_b.append(f32(f"{h}readout_projects.{i}.0.bias"))
         self.oc = [sd[f"{h}projects.{i}.weight"].shape[0] for i in range(4)]
         self.features = sd[h + "scratch.layer1_rn.weight"].shape[0]
-        self.proj_w = [lin(f32(f"{h}projects.{i}.weight"), "tok") for i in range(4)]
+        self.proj_w = [lin(f32(f"{h}projects.{i}.weight"), "proj") for i in range(4)]
         self.proj_b = [f32(f"{h}projects.{i}.bias") for i in range(4)]
-        self.rs0_w, self.rs0_b = convT(f32(h + "resize_layers.0.weight"), f32(h + "resize_layers.0.bias"), 4, "tok")
-        self.rs1_w, self.rs1_b = convT(f32(h + "resize_layers.1.weight"), f32(h + "resize_layers.1.bias"), 2, "tok")
-        self.rs3_w, self.rs3_b = conv3(f32(h + "resize_layers.3.weight"), "tok"), f32(h + "resize_layers.3.bias")
+        self.rs0_w, self.rs0_b = convT(f32(h + "resize_layers.0.weight"), f32(h + "resize_layers.0.bias"), 4, "rs0")
+        self.rs1_w, self.rs1_b = convT(f32(h + "resize_layers.1.weight"), f32(h + "resize_layers.1.bias"), 2, "rs1")
+        self.rs3_w, self.rs3_b = conv3(f32(h + "resize_layers.3.weight"), "rs3"), f32(h + "resize_layers.3.bias")
         if amodal_head:
-            self.ip_w = [conv3(f32(f"{h}input_projection.{i}.0.weight"), "ip") for i in range(4)]
+            self.ip_w = [conv3(f32(f"{h}input_projection.{i}.0.weight"), f"ip{i}") for i in range(4)]
             self.ip_b = [f32(f"{h}input_projection.{i}.0.bias") for i in range(4)]
             self.ip_ln_w = [f32(f"{h}input_projection.{i}.1.weight") for i in range(4)]
             self.ip_ln_b = [f32(f"{h}input_projection.{i}.1.bias") for i in range(4)]
         s = h + "scratch."
-        self.rn_w = [conv3(f32(f"{s}layer{i + 1}_rn.weight"), "rn") for i in range(4)]
+        self.rn_w = [conv3(f32(f"{s}layer{i + 1}_rn.weight"), f"rn{i}") for i in range(4)]
         self.fuse = []
         for k in range(1, 5):
             r = f"{s}refinenet{k}."
-            d = dict(out_w=lin(f32(r + "out_conv.weight"), "out"), out_b=f32(r + "out_conv.bias"))
+            d = dict(out_w=lin(f32(r + "out_conv.weight"), f"out{k - 1}"), out_b=f32(r + "out_conv.bias"))
             for u in (1, 2):
                 for c in (1, 2):
                     w, b = f32(f"{r}resConfUnit{u}.conv{c}.weight"), f32(f"{r}resConfUnit{u}.conv{c}.bias")
@@ -265,7 +269,7 @@ class PackedWeights:
                     if bn + "running_var" in sd:      # use_bn=True: inference BatchNorm folded into the conv (reference blocks.py:70-76)
                         from .functional import fold_batchnorm
                         w, b = fold_batchnorm(w, b, f32(bn + "weight"), f32(bn + "bias"), f32(bn + "running_mean"), f32(bn + "running_var"))
-                    d[f"u{u}c{c}_w"] = conv3(w, "rcu")
+                    d[f"u{u}c{c}_w"] = conv3(w, f"rcu{k - 1}")
                     d[f"u{u}c{c}_b"] = b.contiguous()
             self.fuse.append(d)  # index k-1
         self.oc1_w, self.oc1_b = conv3(f32(s + "output_conv1.weight"), "oc1"), f32(s + "output_conv1.bias")
@@ -309,8 +313,8 @@ class Workspace:
         Fp = _r64(Fch)
         def mm(group):     # an op-typed head tensor holds [hi | lo | hi] segments iff the contraction that READS it is in a split group
             return 3 if group in pw_.split else 1
-        m = mm("tok")
-        first = "ip" if pw_.amodal_head else "rn"     # the contraction that reads the reassembled maps L[i]
+        m = mm("proj")
+        first = "ip" if pw_.amodal_head else "rn"     # the contraction family that reads the reassembled maps L[i]
 
         def z(*shape, dtype=op):
             return torch.zeros(*shape, dtype=dtype, device=device)
@@ -335,20 +339,20 @@ class Workspace:
         oc = pw_.oc
         ocp = [_r64(c) for c in oc]
         self.ocp, self.Fp = ocp, Fp
-        self.t0 = z(P, m * ocp[0])
-        self.t1 = z(P, m * ocp[1])
-        self.pre3 = z(B, ph + 2, pw + 2, m * ocp[3])
-        self.L = [z(B, g[0] + 2, g[1] + 2, mm(first) * ocp[i]) for i, g in enumerate(self.grid)]
+        self.t0 = z(P, mm("rs0") * ocp[0])
+        self.t1 = z(P, mm("rs1") * ocp[1])
+        self.pre3 = z(B, ph + 2, pw + 2, mm("rs3") * ocp[3])
+        self.L = [z(B, g[0] + 2, g[1] + 2, mm(f"{first}{i}") * ocp[i]) for i, g in enumerate(self.grid)]
         if pw_.amodal_head:
             self.ipf = [z(B * g[0] * g[1], oc[i], dtype=torch.float32) for i, g in enumerate(self.grid)]
-            self.L2 = [z(B, g[0] + 2, g[1] + 2, mm("rn") * ocp[i]) for i, g in enumerate(self.grid)]
+            self.L2 = [z(B, g[0] + 2, g[1] + 2, mm(f"rn{i}") * ocp[i]) for i, g in enumerate(self.grid)]
         self.rnx = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
-        self.rnr = [z(B, g[0] + 2, g[1] + 2, mm("rcu") * Fp) for g in self.grid]
-        self.tmpa = [z(B, g[0] + 2, g[1] + 2, mm("rcu") * Fp) for g in self.grid]
+        self.rnr = [z(B, g[0] + 2, g[1] + 2, mm(f"rcu{i}") * Fp) for i, g in enumerate(self.grid)]
+        self.tmpa = [z(B, g[0] + 2, g[1] + 2, mm(f"rcu{i}") * Fp) for i, g in enumerate(self.grid)]
         self.r = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
         self.s = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
-        self.sr = [z(B, g[0] + 2, g[1] + 2, mm("rcu") * Fp) for g in self.grid]
-        self.u = [z(B * g[0] * g[1], mm("out") * Fp) for g in self.grid]
+        self.sr = [z(B, g[0] + 2, g[1] + 2, mm(f"rcu{i}") * Fp) for i, g in enumerate(self.grid)]
+        self.u = [z(B * g[0] * g[1], mm(f"out{i}") * Fp) for i, g in enumerate(self.grid)]
         self.zf = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
         g0 = self.grid[0]
         self.g296 = (2 * g0[0], 2 * g0[1])
@@ -368,12 +372,6 @@ GRAPH_MODE = os.environ.get("ADA_GRAPH", "auto")
 GRAPH_AUTO_PIXELS = int(os.environ.get("ADA_GRAPH_AUTO_PIXELS", str(518 * 518)))
 # Bounds of the per-shape caches (LRU): a variable-resolution stream of single images must not grow device memory without limit.  A shape is
 # captured only on its SECOND sighting (a one-off resolution pays no extra warm-up forward, synchronise and empty_cache).
-# Dual pipeline (ADA_DUAL): batches of >= DUAL_MIN_BATCH images run as TWO half-batch pipelines on two streams restricted to complementary halves
-# of every XCD's compute units (ada_stream_create_cu_mask), their launches enqueued alternately block by block.  The two pipelines drift apart
-# by a few launches, so the HBM-bound launches of one (LayerNorm, resizes, the fp32-residual epilogues: no FLOPs, ~15 % of a step) run beside
-# MFMA-bound launches of the other instead of serialising with them.  "1" = CU-masked streams, "plain" = two ordinary streams, "0" = off.
-DUAL_MODE = os.environ.get("ADA_DUAL", "0")
-DUAL_MIN_BATCH = int(os.environ.get("ADA_DUAL_MIN_BATCH", "8"))
 MAX_GRAPHS = int(os.environ.get("ADA_GRAPH_CACHE", "4"))
 MAX_WORKSPACES = int(os.environ.get("ADA_WORKSPACE_CACHE", "6"))
 
@@ -421,7 +419,6 @@ class DepthEngine:
         self._ws: "OrderedDict[tuple, Workspace]" = OrderedDict()
         self._graphs: "OrderedDict[tuple, object]" = OrderedDict()   # key -> _GraphedForward | False (capture refused) | int (sightings)
         self._lock = threading.Lock()
-        self._dual_streams: Dict[str, tuple] = {}
 
     def max_batch(self, H: int, W: int) -> int:
         if H * W > MAX_ROWS:
@@ -429,8 +426,8 @@ class DepthEngine:
                               "use hip_ext.tiling.tiled_amodal_forward / tiled_raw_forward")
         return max(1, MAX_ROWS // (H * W))
 
-    def workspace(self, B, H, W, device, slot: int = 0) -> Workspace:
-        key = (B, H, W, str(device), slot)
+    def workspace(self, B, H, W, device) -> Workspace:
+        key = (B, H, W, str(device))
         ws = self._ws.get(key)
         if ws is None:
             while len(self._ws) >= max(1, MAX_WORKSPACES):
@@ -470,8 +467,6 @@ class DepthEngine:
         if not x.is_cuda:
             raise HipExtError("DepthEngine.forward: input must live on a HIP device (no CPU fallback in the product path)")
         norm = self.normalise_input if normalise is None else bool(normalise)
-        if DUAL_MODE != "0" and x.shape[0] >= DUAL_MIN_BATCH and not torch.cuda.is_current_stream_capturing():
-            return self._forward_dual(x, guide, norm)
         mode = GRAPH_MODE
         use = mode == "1" or (mode == "auto" and x.shape[0] * x.shape[-2] * x.shape[-1] <= GRAPH_AUTO_PIXELS)
         # replay bypasses the Python wrappers: with a KernelTimer or a tile log attached the launches must be issued one by one
@@ -502,60 +497,7 @@ class DepthEngine:
             return self._forward(x, guide, norm)
         return g(x, guide)
 
-    def _streams_for(self, device):
-        key = str(device)
-        st = self._dual_streams.get(key)
-        if st is None:
-            if DUAL_MODE == "plain":
-                st = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
-            else:
-                from . import cu_mask_stream
-                n = torch.cuda.get_device_properties(device).multi_processor_count
-                low = [i < n // 2 for i in range(n)]      # consecutive mask bits go round-robin over the XCDs: half of EVERY XCD
-                st = (cu_mask_stream(low, n, device), cu_mask_stream([not b for b in low], n, device))
-            self._dual_streams[key] = st
-        return st
-
-    def _forward_dual(self, x: torch.Tensor, guide: Optional[torch.Tensor], norm: Optional[bool] = None) -> torch.Tensor:
-        """Two half-batch pipelines on complementary compute-unit sets (see DUAL_MODE); bit-identical to the single-stream forward
-        (the kernels are batch invariant)."""
-        B = x.shape[0]
-        half = (B + 1) // 2
-        dev = x.device
-        main = torch.cuda.current_stream(dev)
-        streams = self._streams_for(dev)
-        out = torch.empty(B, 1, x.shape[-2], x.shape[-1], dtype=torch.float32, device=dev)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        spans = ((0, half), (half, B))
-        gens = []
-        for slot, (s, (lo, hi)) in enumerate(zip(streams, spans)):
-            s.wait_event(ready)
-            gens.append(self._forward_steps(x[lo:hi], None if guide is None else guide[lo:hi], slot, norm))
-        live = [True, True]
-        while any(live):      # alternate the enqueues block by block: neither pipeline starts a whole forward's worth of launches late
-            for slot, (s, (lo, hi)) in enumerate(zip(streams, spans)):
-                if not live[slot]:
-                    continue
-                with torch.cuda.stream(s):
-                    res = next(gens[slot])
-                    if res is not None:
-                        out[lo:hi].copy_(res)
-                        live[slot] = False
-                        done = torch.cuda.Event()
-                        done.record(s)
-                        main.wait_event(done)
-        return out
-
     def _forward(self, x: torch.Tensor, guide: Optional[torch.Tensor], norm: Optional[bool] = None) -> torch.Tensor:
-        for res in self._forward_steps(x, guide, 0, norm):
-            if res is not None:
-                return res
-        raise AssertionError("unreachable")
-
-    def _forward_steps(self, x: torch.Tensor, guide: Optional[torch.Tensor], slot: int, norm: Optional[bool] = None):
-        """The launch sequence as a generator: yields None after the token stage and after every transformer block (so two pipelines can be
-        enqueued alternately), and finally the output tensor."""
         w = self.w
         if not x.is_cuda:
             raise HipExtError("DepthEngine.forward: input must live on a HIP device (no CPU fallback in the product path)")
@@ -568,7 +510,7 @@ class DepthEngine:
                 raise HipExtError(f"guide tensor with {w.guide_channels} channels required")
             guide = guide.contiguous().float()
         x = x.contiguous().float()
-        ws = self.workspace(B, H, W, x.device, slot)
+        ws = self.workspace(B, H, W, x.device)
         D, heads = w.dim, w.heads
         ph, pw = ws.ph, ws.pw
         Np = ph * pw
@@ -584,7 +526,6 @@ class DepthEngine:
         k_igemm(M=P, N=D, K=w.pe_k, k_alg=(3 + w.guide_channels) * 196, A=ws.a_pe, lda=w.pe_k, W=w.pe_w, bias=w.pe_b, res=pos, ldr=D, res_row_mod=Np, res_row_off=1,
                 flags=EP_BIAS | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, map_f32=MAP_TOKEN, map_h=Np)
         k_write_cls(ws.x, B, N, D, w.cls, pos)
-        yield None
 
         # ---- transformer blocks ------------------------------------------------------------------
         taps = TAPS[w.encoder]
@@ -630,14 +571,13 @@ class DepthEngine:
             if i in taps:  # shared final LayerNorm on the tap, cls row dropped (dinov2.py:337-340)
                 tap = ws.taps[taps.index(i)]
                 k_layernorm(ws.x, D, P, D, w.norm_w, w.norm_b, LN_EPS, group_in=N, skip=1, out_op=tap, ld_op=tap.shape[1],
-                            split_seg=D if "tok" in w.split else 0)
+                            split_seg=D if "proj" in w.split else 0)
                 if w.readout:   # the class token of every image (row b * N of the token matrix): input row stride N * D
                     j = taps.index(i)
                     k_layernorm(ws.x, N * D, B, D, w.norm_w, w.norm_b, LN_EPS, out_op=ws.cls_op[j], ld_op=ws.cls_op[j].shape[1],
-                                split_seg=D if "tok" in w.split else 0)
-            yield None
+                                split_seg=D if "proj" in w.split else 0)
 
-        yield self._head(ws, B)
+        return self._head(ws, B)
 
     def _head(self, ws: Workspace, B: int) -> torch.Tensor:
         w = self.w
@@ -650,7 +590,7 @@ class DepthEngine:
         rows = [B * g[0] * g[1] for g in grid]
 
         ocp, Fp = ws.ocp, ws.Fp
-        first = "ip" if w.amodal_head else "rn"     # the group of the contraction that reads the reassembled maps
+        first = "ip" if w.amodal_head else "rn"     # the family of the contraction that reads the reassembled maps L[i]
 
         def S(group, seg):   # split_seg argument of a producer whose CONSUMER (a contraction of `group`) reads [hi | lo | hi] segments of width seg
             return seg if group in w.split else 0
@@ -663,22 +603,22 @@ class DepthEngine:
                 k_igemm(M=B, N=D, K=KDr, k_alg=D, A=ws.cls_op[i], lda=KDr, W=w.ro_wc[i], bias=w.ro_b[i], flags=EP_BIAS, out_f32=ws.cls_bias[i], ldo_f32=D)
                 for b in range(B):
                     k_igemm(M=Np, N=D, K=KDr, k_alg=D, A=ws.taps[i][b * Np:(b + 1) * Np], lda=KDr, W=w.ro_wx[i], bias=ws.cls_bias[i][b],
-                            flags=EP_BIAS | EP_GELU, out_op=ws.taps_ro[i][b * Np:(b + 1) * Np], ldo_op=ws.taps_ro[i].shape[1], split_seg=S("tok", D))
+                            flags=EP_BIAS | EP_GELU, out_op=ws.taps_ro[i][b * Np:(b + 1) * Np], ldo_op=ws.taps_ro[i].shape[1], split_seg=S("proj", D))
             taps_in = ws.taps_ro
         # ---- reassemble: 1x1 project + resize (dpt.py:171-173) -> zero-bordered NHWC operand tensors -----
         KD = ws.taps[0].shape[1]
-        k_igemm(M=P, N=oc[0], K=KD, k_alg=D, A=taps_in[0], lda=KD, W=w.proj_w[0], bias=w.proj_b[0], flags=EP_BIAS, out_op=ws.t0, ldo_op=ws.t0.shape[1], split_seg=S("tok", ocp[0]))
+        k_igemm(M=P, N=oc[0], K=KD, k_alg=D, A=taps_in[0], lda=KD, W=w.proj_w[0], bias=w.proj_b[0], flags=EP_BIAS, out_op=ws.t0, ldo_op=ws.t0.shape[1], split_seg=S("rs0", ocp[0]))
         k_igemm(M=P, N=16 * oc[0], K=ws.t0.shape[1], k_alg=oc[0], A=ws.t0, lda=ws.t0.shape[1], W=w.rs0_w, bias=w.rs0_b, flags=EP_BIAS,
-                out_op=ws.L[0], ldo_op=ws.L[0].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=4, shuffle_c=oc[0], split_seg=S(first, ocp[0]))
-        k_igemm(M=P, N=oc[1], K=KD, k_alg=D, A=taps_in[1], lda=KD, W=w.proj_w[1], bias=w.proj_b[1], flags=EP_BIAS, out_op=ws.t1, ldo_op=ws.t1.shape[1], split_seg=S("tok", ocp[1]))
+                out_op=ws.L[0], ldo_op=ws.L[0].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=4, shuffle_c=oc[0], split_seg=S(first + "0", ocp[0]))
+        k_igemm(M=P, N=oc[1], K=KD, k_alg=D, A=taps_in[1], lda=KD, W=w.proj_w[1], bias=w.proj_b[1], flags=EP_BIAS, out_op=ws.t1, ldo_op=ws.t1.shape[1], split_seg=S("rs1", ocp[1]))
         k_igemm(M=P, N=4 * oc[1], K=ws.t1.shape[1], k_alg=oc[1], A=ws.t1, lda=ws.t1.shape[1], W=w.rs1_w, bias=w.rs1_b, flags=EP_BIAS,
-                out_op=ws.L[1], ldo_op=ws.L[1].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=2, shuffle_c=oc[1], split_seg=S(first, ocp[1]))
+                out_op=ws.L[1], ldo_op=ws.L[1].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=2, shuffle_c=oc[1], split_seg=S(first + "1", ocp[1]))
         k_igemm(M=P, N=oc[2], K=KD, k_alg=D, A=taps_in[2], lda=KD, W=w.proj_w[2], bias=w.proj_b[2], flags=EP_BIAS,
-                out_op=ws.L[2], ldo_op=ws.L[2].shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S(first, ocp[2]))
+                out_op=ws.L[2], ldo_op=ws.L[2].shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S(first + "2", ocp[2]))
         k_igemm(M=P, N=oc[3], K=KD, k_alg=D, A=taps_in[3], lda=KD, W=w.proj_w[3], bias=w.proj_b[3], flags=EP_BIAS,
-                out_op=ws.pre3, ldo_op=ws.pre3.shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S("tok", ocp[3]))
+                out_op=ws.pre3, ldo_op=ws.pre3.shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S("rs3", ocp[3]))
         self._conv3(ws.pre3, w.rs3_w, rows[3], oc[3], grid[3], stride=2, cin=oc[3], bias=w.rs3_b, flags=EP_BIAS,
-                    out_op=ws.L[3], ldo_op=ws.L[3].shape[3], map_op=MAP_PAD, map_h=grid[3][0], map_w=grid[3][1], split_seg=S(first, ocp[3]))
+                    out_op=ws.L[3], ldo_op=ws.L[3].shape[3], map_op=MAP_PAD, map_h=grid[3][0], map_w=grid[3][1], split_seg=S(first + "3", ocp[3]))
 
         # ---- amodal only: input_projection = conv3x3 -> channels-first LN -> ReLU (dpt.py:153-159,178-179) ----
         layers = ws.L
@@ -686,19 +626,19 @@ class DepthEngine:
             for i in range(4):
                 self._conv3(ws.L[i], w.ip_w[i], rows[i], oc[i], grid[i], cin=oc[i], bias=w.ip_b[i], flags=EP_BIAS, out_f32=ws.ipf[i], ldo_f32=oc[i])
                 k_layernorm(ws.ipf[i], oc[i], rows[i], oc[i], w.ip_ln_w[i], w.ip_ln_b[i], LN_EPS, out_op=ws.L2[i],
-                            ld_op=ws.L2[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], relu=True, split_seg=S("rn", ocp[i]))
+                            ld_op=ws.L2[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], relu=True, split_seg=S(f"rn{i}", ocp[i]))
             layers = ws.L2
 
         # ---- layerN_rn (blocks.py:20-24): fp32 copy for the residual adds + ReLU'd operand copy for conv1 ----
         for i in range(4):
             self._conv3(layers[i], w.rn_w[i], rows[i], Fch, grid[i], cin=oc[i], flags=EP_RELU_OP, out_f32=ws.rnx[i], ldo_f32=Fch,
-                        out_op=ws.rnr[i], ldo_op=ws.rnr[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], split_seg=S("rcu", Fp))
+                        out_op=ws.rnr[i], ldo_op=ws.rnr[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], split_seg=S(f"rcu{i}", Fp))
 
         def rcu(i, fw, unit, src_relu_pad, src_f32, **out):
             """ResidualConvUnit (blocks.py:57-80) at grid i: conv2(relu(conv1(relu(x)))) + x."""
             g = grid[i]
             self._conv3(src_relu_pad, fw[f"u{unit}c1_w"], rows[i], Fch, g, cin=Fch, bias=fw[f"u{unit}c1_b"], flags=EP_BIAS | EP_RELU_OP,
-                        out_op=ws.tmpa[i], ldo_op=ws.tmpa[i].shape[3], map_op=MAP_PAD, map_h=g[0], map_w=g[1], split_seg=S("rcu", Fp))
+                        out_op=ws.tmpa[i], ldo_op=ws.tmpa[i].shape[3], map_op=MAP_PAD, map_h=g[0], map_w=g[1], split_seg=S(f"rcu{i}", Fp))
             self._conv3(ws.tmpa[i], fw[f"u{unit}c2_w"], rows[i], Fch, g, cin=Fch, bias=fw[f"u{unit}c2_b"], res=src_f32, ldr=Fch,
                         flags=EP_BIAS | EP_RESIDUAL, **out)
 
@@ -707,14 +647,14 @@ class DepthEngine:
         s_f32, s_pad = ws.rnx[3], ws.rnr[3]
         for i in (3, 2, 1, 0):
             fw = w.fuse[i]
-            rcu(i, fw, 2, s_pad, s_f32, out_op=ws.u[i], ldo_op=ws.u[i].shape[1], split_seg=S("out", Fp))
+            rcu(i, fw, 2, s_pad, s_f32, out_op=ws.u[i], ldo_op=ws.u[i].shape[1], split_seg=S(f"out{i}", Fp))
             k_igemm(M=rows[i], N=Fch, K=ws.u[i].shape[1], k_alg=Fch, A=ws.u[i], lda=ws.u[i].shape[1], W=fw["out_w"], bias=fw["out_b"], flags=EP_BIAS,
                     out_f32=ws.zf[i], ldo_f32=Fch)
             if i > 0:
                 j = i - 1
                 rcu(j, w.fuse[j], 1, ws.rnr[j], ws.rnx[j], out_f32=ws.r[j], ldo_f32=Fch)
                 k_bilinear(ws.zf[i], Fch, B, grid[i][0], grid[i][1], grid[j][0], grid[j][1], Fch, add=ws.r[j], ld_add=Fch,
-                           out_f32=ws.s[j], ld_f32=Fch, out_op=ws.sr[j], ld_op=ws.sr[j].shape[3], map_op=MAP_PAD, relu=True, split_seg=S("rcu", Fp))
+                           out_f32=ws.s[j], ld_f32=Fch, out_op=ws.sr[j], ld_op=ws.sr[j].shape[3], map_op=MAP_PAD, relu=True, split_seg=S(f"rcu{j}", Fp))
                 s_f32, s_pad = ws.s[j], ws.sr[j]
         g2 = ws.g296
         k_bilinear(ws.zf[0], Fch, B, grid[0][0], grid[0][1], g2[0], g2[1], Fch, out_op=ws.p1, ld_op=ws.p1.shape[3], map_op=MAP_PAD, split_seg=S("oc1", Fp))

@@ -115,9 +115,20 @@ import os as _os
 _FOLD_LN_DEFAULT = _os.environ.get("ADA_FOLD_LN", "0") == "1"
 
 
+# Head precision policy for "auto" (measured on MI355X against the reference goldens, profiles/r03_e_head_split_sweep.txt):
+#   sigmoid heads of ViT-B / ViT-L (the benchmarked models)  -> single precision everywhere (6.6e-4 .. 8.2e-4)
+#   ViT-S (64-feature head) and every 'ssi' head             -> every head contraction in split precision (1.8e-3 -> 6.9e-4; cheap models)
+#   raw (ReLU) ViT-G, features 384                           -> only the contractions whose operand rounding shows in the output and that are
+#                                                               cheap: the tail conv, the 1x1 out_convs and projects, the three coarse
+#                                                               layer_rn convs, resize_layers 1 and 3.  8 x 1022^2: 9.1e-4 at 36.6 images/s
+#                                                               (everything split: 8.7e-4 at 28.4; nothing: 1.3e-3 at 41.3).  Splitting the
+#                                                               ResidualConvUnit convs makes ViT-G parity WORSE (1.13e-3 -> 1.31e-3).
+_RAW_VITG_SPLIT = ("oc2", "out", "rn1", "rn2", "rn3", "proj", "rs1", "rs3")
+
+
 def _head_split_policy(mode, encoder, final_act):
-    """Which layer groups of the DPT head (hip_ext.engine.HEAD_GROUPS) run in split precision.  ``mode``: "auto" | "split" (all groups) |
-    "single" (none) | a comma-separated string / iterable of group names.  ADA_HEAD_SPLIT overrides "auto" (experiments)."""
+    """Which contractions of the DPT head (hip_ext.engine.HEAD_GROUPS / HEAD_ALIASES) run in split precision.  ``mode``: "auto" |
+    "split" (all) | "single" (none) | a comma-separated string / iterable of names.  ADA_HEAD_SPLIT overrides "auto" (experiments)."""
     from hip_ext.engine import HEAD_GROUPS
     if mode == "auto" and _os.environ.get("ADA_HEAD_SPLIT") is not None:
         mode = _os.environ["ADA_HEAD_SPLIT"]
@@ -126,7 +137,11 @@ def _head_split_policy(mode, encoder, final_act):
     if mode in ("single", "", "none"):
         return frozenset()
     if mode == "auto":
-        return frozenset(HEAD_GROUPS) if (final_act != "sigmoid" or encoder == "vits") else frozenset()
+        if final_act == "sigmoid" and encoder != "vits":
+            return frozenset()
+        if final_act == "relu" and encoder == "vitg":
+            return frozenset(_RAW_VITG_SPLIT)
+        return frozenset(HEAD_GROUPS)
     if isinstance(mode, str):
         mode = [g for g in mode.split(",") if g]
     return frozenset(mode)

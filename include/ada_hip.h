@@ -282,16 +282,6 @@ int ada_tile_blend_fwd(const float* tiles, int32_t batch, int32_t n_tiles, int32
                        const int32_t* origin_y, const int32_t* origin_x, int32_t height, int32_t width,
                        int32_t ramp, float* out, void* stream);
 
-/* ------------------------------------------------------------------------------------------
- * Compute-unit partitioned streams (no counterpart in the reference: its inference is one stream, infer.py:59-69).
- * ada_stream_create_cu_mask creates a HIP stream restricted to the CUs whose bit is set in mask[words] (bit i -> word i / 32;
- * consecutive bits go round-robin over the XCDs, so the low half of the bits is "half of every XCD").  The forward engine runs two
- * half-batch pipelines on two complementary streams: the HBM-bound launches of one (LayerNorm, resizes, fp32-residual epilogues)
- * overlap the MFMA-bound launches of the other.  Streams are plain hipStream_t handles; destroy with ada_stream_destroy.
- * ---------------------------------------------------------------------------------------- */
-int ada_stream_create_cu_mask(const uint32_t* mask, int32_t words, void** stream_out);
-int ada_stream_destroy(void* stream);
-
 /* Hardware self-test used by the GPU test-suite: checks the MFMA / LDS-transpose fragment layouts the
  * kernels assume against a scalar computation on the device.  Returns 0 when they hold,
  * a positive bit mask of failed probes otherwise.  scratch: >= 1 MiB of device memory. */

@@ -13,8 +13,10 @@ import torch  # noqa: E402
 
 from _cases import build_product_model, case_inputs, load_golden, rel_l1, synth_state_dict  # noqa: E402
 
-SUBSETS = ["", "oc2", "oc1,oc2", "oc1,oc2,out", "oc1,oc2,rcu", "oc1,oc2,rn", "oc1,oc2,tok", "oc1,oc2,ip", "rcu", "rn,tok", "oc1,oc2,rn,tok",
-           "oc1,oc2,rn,tok,out", "tok,ip,rn,rcu,out", "tok,ip,rn,rcu,out,oc1,oc2"]
+SUBSETS = ["", "oc2,out", "oc2,out,rn1,rn2,rn3", "oc2,out,rn2,rn3", "oc2,out,rn", "oc2,out,rn1,rn2,rn3,proj", "oc2,out,rn1,rn2,rn3,proj,rs1,rs3",
+           "oc1,oc2,out,rn1,rn2,rn3", "oc2,out0,rn1,rn2,rn3", "oc2,out,rn3", "tok,ip,rn,out,oc1,oc2", "tok,ip,rn,rcu,out,oc1,oc2"]
+if os.environ.get("SUBSETS"):
+    SUBSETS = os.environ["SUBSETS"].split(";")
 
 
 def main():

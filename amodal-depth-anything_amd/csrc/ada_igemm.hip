@@ -201,13 +201,23 @@ ADA_DEV void rowstat_store(const IgemmDev& p, float4 v, long row, int group, boo
     if (leader && valid) *(float2*)(p.rowstat_out + (row * p.rowstat_groups + group) * 2) = make_float2(s1, s2);
 }
 
-// LOOP: main loop of the kernel -- 0 single-barrier loop (every tile shape), 1 phased ping-pong loop (256x256x64 tile with 2 x 4 waves).
+#include "ada_igemm_pipe4.inc"
+
+// LOOP: main loop of the kernel -- 0 single-barrier loop (every tile shape),
+// 2 hand-scheduled one-wave-per-SIMD loop (256x256x64 tile with 2 x 2 waves, wave tile 128 x 128, 256 accumulators in AGPRs -- the
+// library kernel's shape, profiles/r03_b_vendor_gemm_kernel_anatomy.txt: 1.5x fewer LDS fragment bytes per FLOP than the 8-wave tile).
+// Its instruction stream is generated assembly (tools/gen_pipe4_asm.py -> ada_igemm_pipe4.inc); the accumulators never exist as C++ values:
+// the epilogue's dump() fetches them from the AGPRs.  Measured (profiles/r03_i_gemm_4wave_asm_loop.txt): the main loop ties the 8-wave loop at
+// K = 1024 and beats it -- and the library -- on long k-loops (fc2 shape with a bias epilogue: 1203 vs 1111 vs 1096 TF/s), but with one wave per
+// SIMD the prologue and the VALU / latency-bound fused epilogues run slower; net it wins from K >= 8192 (the 9216-deep head convs: -7 ... -12 %),
+// which is where launch_epi selects it.  (Round 2's phased 8-wave ping-pong loop measured the same as the single-barrier loop and left the build.)
 // (A third loop that loaded the weight fragments straight to registers -- LDS traffic 256 -> 160 KB per k-tile -- passed every test and
 // ran 30 % slower: fragment-shaped loads are expensive on the texture path.  profiles/r02_g_gemm_b_direct_ab.txt)
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, int LOOP = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && BM * BN == 256 * 256) ? 1 : 2) void igemm_kernel(IgemmDev p) {
-    constexpr bool PHASED = LOOP == 1;
-    static_assert(LOOP == 0 || (BM == 256 && BN == 256 && BK == 64 && WAVES_M == 2 && WAVES_N == 4), "the phased main loop is written for the 256x256x64 tile, 2 x 4 waves");
+    constexpr bool PIPE4 = LOOP == 2;
+    static_assert(LOOP == 0 || LOOP == 2, "main loops: 0 single-barrier, 2 hand-scheduled 4-wave");
+    static_assert(LOOP != 2 || (BM == 256 && BN == 256 && BK == 64 && WAVES_M == 2 && WAVES_N == 2), "the hand-scheduled main loop is written for the 256x256x64 tile, 2 x 2 waves");
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int NT = NWAVES * 64;
     constexpr int TI = BM / (WAVES_M * 32);
@@ -339,183 +349,35 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 for (int r = 0; r < 4; ++r) acc[i][j][ab][r] = 0.0f;
 
     const int nk = p.K / BK;
-    if constexpr (PHASED) {
-        // ---- phased main loop (cdna_hip_programming.md section 5, "the 256^2 8-phase template"; T3 + T4 + T5) -------------------
-        // A k-tile is computed in four phases, one 64 x 32 quadrant of the wave's 128 x 64 output tile each (16 MFMAs over the
-        // whole BK = 64).  A phase is two barrier intervals:   L: fragment reads for this quadrant + ONE half-tile of LDS-DMA copies
-        //                                                      M: s_setprio 1, 16 MFMAs, s_setprio 0
-        // and the two wave groups (wm = 0: waves 0-3, wm = 1: waves 4-7; waves w and w + 4 share a SIMD) run one interval apart, so on
-        // every SIMD one wave issues MFMAs while its partner reads LDS and issues copies.  Quadrant order (A-lo,B-lo) (A-lo,B-hi)
-        // (A-hi,B-hi) (A-hi,B-lo): 12 / 4 / 8 / 0 fragment reads; the B regions of a stage are last read in phase 1, the A regions
-        // in phase 2.  Copies are never drained inside the loop: the half-tiles of k-tile t+1 / t+2 are issued 3-8 intervals before
-        // their first read and each group waits ONCE per k-tile with a counted vmcnt that leaves its youngest copies in flight.
-        //   issue schedule (X(u) = half-tile X of k-tile u, stage u & 1), chosen so that every copy is issued at least one barrier
-        //   after the last read of the region it overwrites has RETIRED (reads retire in the M interval after their L interval):
-        //       group 1:  p0 A0(t+1)   p1 A1(t+1)   p2 B0(t+2)   p3 B1(t+2)   wait vmcnt(4) at the end of L(p3)
-        //       group 0:  p0 B1(t+1)   p1 A0(t+1)   p2 A1(t+1)   p3 B0(t+2)   wait vmcnt(2) at the end of M(p3)
-        //   both waits end at the same barrier, after which k-tile t+1 is complete in LDS for every wave.
-        const int wm_ = wave / WAVES_N, wn_ = wave % WAVES_N;
-        const bool g1 = wm_ == 1;   // wave-uniform
+    if constexpr (PIPE4) {
+        // everything between here and the epilogue's first dump() is the generated asm: fragments in v[0:127], accumulators in a[0:255]
         const int l15 = lane & 15, q4 = lane >> 4;
         const unsigned lds0 = (unsigned)(size_t)smem;
-        unsigned a_base[2], b_base[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const unsigned coff = (unsigned)(((4 * s2 + q4) ^ ((l15 >> 1) & 7)) * 16);
-            a_base[s2] = lds0 + (unsigned)((wm_ * 128 + l15) * RB) + coff;
-            b_base[s2] = lds0 + (unsigned)(A_BYTES + (wn_ * 64 + l15) * RB) + coff;
+        const unsigned coff0 = (unsigned)((q4 ^ ((l15 >> 1) & 7)) * 16);
+        const unsigned abase = lds0 + (unsigned)((wm * 128 + l15) * RB) + coff0;
+        const unsigned bbase = lds0 + (unsigned)(A_BYTES + (wn * 128 + l15) * RB) + coff0;
+        const unsigned m0s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)wave * 1024u));
+        constexpr unsigned OOB = 0x7fffffffu;     // a scalar offset beyond num_records: the copy zero-fills without fetching
+        long a0o, b0o, a1o = 0, b1o = 0, a2o = 0, b2o = 0;
+        slab_offsets(0, a0o, b0o);
+        if (nk > 1) slab_offsets(1, a1o, b1o);
+        if (nk > 2) slab_offsets(2, a2o, b2o);
+        unsigned period = 0x7fffffffu, cnt = 0, jump = 0;
+        if (p.a_mode != ADA_A_PLAIN) {   // 3x3 conv: consecutive k-tiles of an input row (three taps) are contiguous; every 3 * cps k-tiles the
+            period = (unsigned)(3 * cps);   // A window moves down one padded input row
+            cnt = 2u % period;
+            jump = (unsigned)(((long)(p.Wp - 3) * p.lda) * 2);
         }
-        auto copy_half = [&](int stage, int is_b, int h, long aoff, long boff) {   // one half-tile = passes 2h, 2h+1
-            char* dst = smem + stage * STAGE_BYTES + wave * 1024 + (is_b ? A_BYTES : 0);
-            if (is_b) {
-#pragma unroll
-                for (int it = 0; it < 2; ++it)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(dst + (2 * h + it) * (NT * 16)), 16,
-                                                             (int)(h ? b_off[2 + it] : b_off[it]), (int)(boff * 2), 0, 0);
-            } else {
-#pragma unroll
-                for (int it = 0; it < 2; ++it)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(dst + (2 * h + it) * (NT * 16)), 16,
-                                                             (int)(h ? a_off[2 + it] : a_off[it]), (int)(aoff * 2), 0, 0);
-            }
+        // the asm needs the two buffer resources in SGPRs: rebuild them from readfirstlane'd pointer halves so that their uniformity is
+        // provable (the tile bases come out of float-reciprocal divisions, i.e. VALU registers -- cdna_hip_programming.md T20)
+        auto uniform_rsrc = [](const void* ptr) {
+            const unsigned long long v = (unsigned long long)ptr;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+            return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x20000);
         };
-        opx8 af[2][2][2], bf[2][2][2];   // [block in quadrant][16-row half][k half]
-        auto read_a = [&](auto stage_tag, auto qi_tag) {
-            (void)af; (void)a_base;   // asm operands alone do not make a generic lambda capture (clang 22)
-            constexpr int ST = decltype(stage_tag)::value, QI = decltype(qi_tag)::value;
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2)
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[ii][a][s2]) : "v"(a_base[s2] + (unsigned)(ST * STAGE_BYTES)), "i"(((2 * QI + ii) * 32 + a * 16) * RB));
-        };
-        auto read_b = [&](auto stage_tag, auto qj_tag) {
-            (void)bf; (void)b_base;
-            constexpr int ST = decltype(stage_tag)::value, QJ = decltype(qj_tag)::value;
-#pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[QJ][b2][s2]) : "v"(b_base[s2] + (unsigned)(ST * STAGE_BYTES)), "i"((QJ * 32 + b2 * 16) * RB));
-        };
-        auto mfma_quadrant = [&](auto qi_tag, auto qj_tag) {
-            constexpr int QI = decltype(qi_tag)::value, QJ = decltype(qj_tag)::value;
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-#pragma unroll
-                        for (int b2 = 0; b2 < 2; ++b2)
-                            acc[2 * QI + ii][QJ][2 * a + b2] = mfma16(af[ii][a][s2], bf[QJ][b2][s2], acc[2 * QI + ii][QJ][2 * a + b2]);
-            __builtin_amdgcn_s_setprio(0);
-        };
-        // barrier that ends an L interval: the fragment reads issued in it retire right behind it
-        // optional s_memtime anatomy (ada_debug_set_timestamps): [0] L interval + barrier + fragment-read wait, [1] MFMA issue,
-        // [2] barrier after the MFMAs -- accumulated per wave, written by waves 0 and 4
-        unsigned long long tph[3] = {0, 0, 0}, tprev = 0;
-        auto stamp = [&](int k) {
-            if (p.dbg) {
-                const unsigned long long t = __builtin_amdgcn_s_memtime();
-                tph[k] += t - tprev;
-                tprev = t;
-            }
-        };
-        auto l_to_m = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            stamp(0);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto m_to_l = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            stamp(1);
-            __builtin_amdgcn_s_barrier();
-            stamp(2);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-
-        auto k_tile = [&](auto stage_tag, int t) {
-            constexpr int ST = decltype(stage_tag)::value;       // stage of k-tile t
-            const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
-            long a1 = 0, b1 = 0, a2 = 0, b2o = 0;
-            if (has1) slab_offsets(t + 1, a1, b1);
-            if (has2) slab_offsets(t + 2, a2, b2o);
-            // ---- phase 0: quadrant (A-lo, B-lo) ----
-            read_b(stage_tag, I0{});
-            read_a(stage_tag, I0{});
-            if (has1) { if (g1) copy_half(ST ^ 1, 0, 0, a1, b1); else copy_half(ST ^ 1, 1, 1, a1, b1); }
-            l_to_m();
-            mfma_quadrant(I0{}, I0{});
-            m_to_l();
-            // ---- phase 1: (A-lo, B-hi) ----
-            read_b(stage_tag, I1{});
-            if (has1) { if (g1) copy_half(ST ^ 1, 0, 1, a1, b1); else copy_half(ST ^ 1, 0, 0, a1, b1); }
-            l_to_m();
-            mfma_quadrant(I0{}, I1{});
-            m_to_l();
-            // ---- phase 2: (A-hi, B-hi) ----
-            read_a(stage_tag, I1{});
-            if (g1) { if (has2) copy_half(ST, 1, 0, a2, b2o); } else { if (has1) copy_half(ST ^ 1, 0, 1, a1, b1); }
-            l_to_m();
-            mfma_quadrant(I1{}, I1{});
-            m_to_l();
-            // ---- phase 3: (A-hi, B-lo), no fragment reads ----
-            if (has2) { if (g1) copy_half(ST, 1, 1, a2, b2o); else copy_half(ST, 1, 0, a2, b2o); }
-            if (g1 && has1) {
-                if (has2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            l_to_m();
-            mfma_quadrant(I1{}, I0{});
-            if (!g1 && has1) {
-                if (has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            m_to_l();
-        };
-
-        // prologue: k-tile 0 completely, plus the half-tiles of k-tile 1 that the steady-state schedule issued "before the loop"
-        {
-            long a0o, b0o, a1 = 0, b1 = 0;
-            slab_offsets(0, a0o, b0o);
-            copy_half(0, 0, 0, a0o, b0o);
-            copy_half(0, 0, 1, a0o, b0o);
-            copy_half(0, 1, 0, a0o, b0o);
-            copy_half(0, 1, 1, a0o, b0o);
-            if (nk > 1) {
-                slab_offsets(1, a1, b1);
-                copy_half(1, 1, 0, a1, b1);
-                if (g1) copy_half(1, 1, 1, a1, b1);
-            }
-            if (nk > 1) {
-                if (g1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            if (g1) __builtin_amdgcn_s_barrier();     // group 1 runs one interval behind group 0
-            __builtin_amdgcn_sched_barrier(0);
-            if (p.dbg) tprev = __builtin_amdgcn_s_memtime();
-        }
-        for (int t = 0; t < nk; t += 2) {
-            k_tile(I0{}, t);
-            if (t + 1 < nk) k_tile(I1{}, t + 1);
-        }
-        if (p.dbg && lane == 0 && (wave & 3) == 0) {
-            unsigned long long* d = p.dbg + ((long)blockIdx.x * 2 + (g1 ? 1 : 0)) * 8;
-            d[0] = tph[0]; d[1] = tph[1]; d[2] = tph[2]; d[3] = (unsigned long long)nk;
-        }
-        if (!g1) __builtin_amdgcn_s_barrier();        // balances group 1's extra barrier
+        const __amdgpu_buffer_rsrc_t a_rs = uniform_rsrc(a_tile), b_rs = uniform_rsrc(b_tile);
+        pipe4_main_loop(a_rs, b_rs, a_off, b_off, abase, bbase, m0s0, (unsigned)(a0o * 2), nk > 1 ? (unsigned)(a1o * 2) : OOB, nk > 1 ? 128u : OOB,
+                        (unsigned)(a2o * 2), (unsigned)nk, period, cnt, jump);
     } else {
     {
         long aoff, boff;
@@ -580,7 +442,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             }
         }
     }
-    }  // !PHASED
+    }  // single-barrier loop
 
     // ---- epilogue: transpose through a wave-private LDS slab, then float4 per lane ----------------
     // The wave tile is walked in 32-row x GW-column groups (GW = 64, or 32 for the narrow tiles).
@@ -605,7 +467,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
         for (int jj = 0; jj < GJ; ++jj)
 #pragma unroll
             for (int ab = 0; ab < 4; ++ab) {
-                const f32x4 v = acc[i][g * GJ + jj][ab];
+                f32x4 v;
+                if constexpr (PIPE4) {   // accumulator registers of sub-tile (i, j, ab): a[16 (4 i + j) + 4 ab ...] (tools/gen_pipe4_asm.py areg)
+                    const int ar = 16 * (4 * i + (g * GJ + jj)) + 4 * ab;
+                    float v0, v1, v2, v3;
+                    asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
+                                 : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3) : "i"(ar), "i"(ar + 1), "i"(ar + 2), "i"(ar + 3));
+                    v[0] = v0; v[1] = v1; v[2] = v2; v[3] = v3;
+                } else {
+                    v = acc[i][g * GJ + jj][ab];
+                }
                 const unsigned base = slab_lds + (unsigned)((ab >> 1) * 16 * SW * 4);
                 const int col = jj * 32 + 16 * (ab & 1);   // in floats; the two offsets of ds_write2_b32 count 4-byte units (< 256)
                 asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(base), "v"(v[0]), "v"(v[1]), "i"(col), "i"(col + SW) : "memory");
@@ -760,7 +631,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             };
             // residual rows of the next 32-row pass are requested before this pass is transposed (8-wave tiles: the registers
             // are there; with co-resident workgroups the neighbours' MFMAs cover the latency instead)
-            constexpr bool AHEAD = NWAVES == 8 && TJ <= 2;
+            constexpr bool AHEAD = (NWAVES == 8 && TJ <= 2) || PIPE4;
             float4 rcur[NKI], rnext[AHEAD ? NKI : 1];
 #pragma unroll
             for (int k = 0; k < NKI; ++k) rcur[k] = make_float4(0, 0, 0, 0);
@@ -939,7 +810,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
         };
         // one-pass-ahead prefetch only where a single workgroup owns the CU; with 2-3 co-resident workgroups the other
         // workgroups' MFMAs already cover the latency and the 32 extra VGPRs would spill
-        constexpr bool AHEAD = NWAVES == 8 && TJ <= 2;
+        constexpr bool AHEAD = (NWAVES == 8 && TJ <= 2) || PIPE4;
         float4 rcur[NKI], rnext[AHEAD ? NKI : 1];
 #pragma unroll
         for (int k = 0; k < NKI; ++k) rcur[k] = make_float4(0, 0, 0, 0);
@@ -1025,7 +896,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             }
         }
     }
-    if (!PHASED && p.dbg && tid == 0) {
+    if (!PIPE4 && p.dbg && tid == 0) {
         const unsigned long long t_issued = __builtin_amdgcn_s_memtime();   // epilogue instructions issued, stores in flight
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long* d = p.dbg + (long)blockIdx.x * 8;
@@ -1089,6 +960,10 @@ static inline double tile_time(long M, long N, int bm, int bn, int occ, double e
     return (double)((tiles + slots - 1) / slots) * occ * t;
 }
 
+// main loop of the 256x256 tile: variant 16 forces the hand-scheduled 4-wave loop, 4 the single-barrier 8-wave loop; 0 (default) picks the
+// 4-wave loop where its main loop outweighs its slower prologue / epilogue (measured: k-loops of >= 128 k-tiles)
+static inline bool use_pipe4(const IgemmDev& d) { return d.variant >= 16 || (d.variant == 0 && d.K >= 8192); }
+
 template <int EPI>
 int launch_epi(IgemmDev& d, hipStream_t s, int force) {
     int cfg;
@@ -1114,7 +989,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force) {
     if ((d.flags & ADA_EP_ROWSTATS) && cfg == 0) cfg = 1;
     if constexpr (EPI == EPI_SWIGLU) {
         if (cfg == 4 || cfg == 2) return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
-        if (d.variant >= 8) return launch_cfg<256, 256, 64, 2, 4, EPI, 1>(d, s);
+        if (use_pipe4(d)) return launch_cfg<256, 256, 64, 2, 2, EPI, 2>(d, s);
         return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
     } else if constexpr (EPI == EPI_TAIL) {
         return cfg == 0 ? launch_cfg<256, 32, 64, 4, 1, EPI>(d, s) : launch_cfg<128, 64, 64, 4, 1, EPI>(d, s);
@@ -1125,7 +1000,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force) {
             case 2: return launch_cfg<256, 128, 64, 4, 2, EPI>(d, s);
             case 4: return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
             default:
-                if (d.variant >= 8) return launch_cfg<256, 256, 64, 2, 4, EPI, 1>(d, s);
+                if (use_pipe4(d)) return launch_cfg<256, 256, 64, 2, 2, EPI, 2>(d, s);
                 return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
         }
     }
@@ -1136,11 +1011,11 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force) {
 // ---- tuning / diagnostic hooks (declared in include/ada_hip.h; process-global atomics, not needed for correct operation) ----
 static std::atomic<unsigned long long*> g_dbg{nullptr};
 static std::atomic<int> g_force_tile{-1};
-static std::atomic<int> g_variant{4};   // 4: single-barrier main loop (default); 8: phased ping-pong main loop for the 256x256 tile
+static std::atomic<int> g_variant{0};   // main loop of the 256x256 tile -- 0: by shape (default); 4: single-barrier 8-wave loop; 16: hand-scheduled 4-wave loop
 static std::once_flag g_env_once;
 // debug hook (not part of the stable ABI): override the tile configuration (-1 = heuristic)
 extern "C" void ada_debug_set_tile(int cfg) { g_force_tile.store(cfg, std::memory_order_relaxed); }
-extern "C" void ada_debug_set_variant(int v) { g_variant.store(v >= 8 ? 8 : 4, std::memory_order_relaxed); }
+extern "C" void ada_debug_set_variant(int v) { g_variant.store(v >= 16 ? 16 : v >= 4 ? 4 : 0, std::memory_order_relaxed); }
 extern "C" void ada_debug_set_group(int g) { g_group_override.store(g, std::memory_order_relaxed); }
 extern "C" int ada_debug_last_tile(void) { return g_last_tile; }
 // debug hook (not part of the stable ABI): device buffer of 8 x u64 per workgroup, or NULL to disable

@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["ada_api.hip", "ada_igemm.hip", "ada_attention.hip", "ada_elementwise.hip", "ada_pipeline.hip", "ada_eval.hip", "ada_tail.hip"]
-HEADERS = ["ada_common.h", os.path.join("..", "..", "include", "ada_hip.h")]
+HEADERS = ["ada_common.h", "ada_igemm_pipe4.inc", os.path.join("..", "..", "include", "ada_hip.h")]
 ARCH = "gfx950"
 
 

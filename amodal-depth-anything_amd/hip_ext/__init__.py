@@ -379,7 +379,7 @@ def debug_set_tile(cfg: int = -1):
     load().ada_debug_set_tile(int(cfg))
 
 
-def debug_set_variant(v: int = 4):
+def debug_set_variant(v: int = 0):
     _bump_epoch()
     load().ada_debug_set_variant(int(v))
 

@@ -112,6 +112,10 @@ import os as _os
 # ViT-L bs=32 it removes 47 LayerNorm launches (-2.0 ms) and adds 2.3 ms to the GEMM epilogues that take over their work (the extra
 # operand-typed store of the residual stream, the row-statistics shuffles, the per-row rescale), with 7 % more parity error
 # (profiles/r02_e_layernorm_fold_ab.txt).  ADA_FOLD_LN=1 or ``module.fold_layernorm = True`` turns it on.
+# CAVEAT (why it is an experiment switch, not a product option): the folded path feeds the UN-normalised residual stream to qkv / fc1 as fp16
+# operands and takes the variance as E[x^2] - mean^2 from per-64-column partial sums.  That is fine for the O(1) activations of the synthetic
+# fills; a real DINOv2 checkpoint with massive-activation channels (hundreds) loses accuracy on both counts (cancellation in the variance,
+# operand rounding relative to the outlier).  Check DepthEngine.saturation_report and the parity of your checkpoint before enabling it.
 _FOLD_LN_DEFAULT = _os.environ.get("ADA_FOLD_LN", "0") == "1"
 
 

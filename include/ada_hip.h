@@ -296,11 +296,12 @@ int ada_selftest(void* scratch, int64_t scratch_bytes, void* stream);
  * kernel family are built; what was measured and removed is recorded in DESIGN.md section 8 and profiles/.
  *   ada_debug_set_tile(cfg)      force the ada_igemm tile: 0 256x32, 1 128x64, 2 256x128, 3 256x256,
  *                                4 128x128; -1 = heuristic (default)
- *   ada_debug_set_variant(v)     main loop of the 256x256 tile: 4 = single-barrier loop (default);
- *                                8 = phased ping-pong loop (same speed under the power cap)
+ *   ada_debug_set_variant(v)     main loop of the 256x256 tile: 0 = chosen by shape (default: the hand-scheduled 4-wave loop for
+ *                                k-loops of >= 128 k-tiles, the single-barrier 8-wave loop otherwise); 4 = always the 8-wave loop;
+ *                                16 = always the hand-scheduled 4-wave loop (generated assembly, csrc/ada_igemm_pipe4.inc)
  *   ada_debug_set_group(g)       force the column-group width of the tile order (0 = traffic model)
  *   ada_debug_last_tile()        tile code of the calling thread's most recent ada_igemm launch
- *                                (+100 when the phased main loop ran), -1 before the first launch
+ *                                (+200 when the hand-scheduled 4-wave main loop ran), -1 before the first launch
  *   ada_debug_set_timestamps(p)  device buffer of 8 x u64 per workgroup receiving s_memtime stamps
  *                                of the single-barrier loop, or NULL (default)
  *   ada_debug_set_attention_variant(v)  5 = 4-wave kernel with the softmax interleaved between its MFMAs (default),

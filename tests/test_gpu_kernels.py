@@ -410,10 +410,10 @@ def test_patchify_split_precision(hip):
 # Every tile configuration x every epilogue: the heuristic of ada_igemm picks the 256x256 tile only
 # for problems with hundreds of tiles, so the small shapes above never reach the kernel the benchmark spends 70 % of its
 # time in.  These tests force each tile (ada_debug_set_tile) and both main loops of the 256x256 tile
-# (ada_debug_set_variant: 8 = phased ping-pong loop, 4 = single-barrier loop) on problems that span >= 3 tile rows, end in
+# (ada_debug_set_variant: 16 = hand-scheduled 4-wave loop, 4 = single-barrier 8-wave loop) on problems that span >= 3 tile rows, end in
 # a ragged tile, and (for the wide ones) engage the column-group tile order.
 # =====================================================================================================================
-TILE_CASES = [(0, 4), (1, 4), (2, 4), (3, 8), (3, 4), (4, 4)]   # (tile cfg, main-loop variant: 4 single barrier, 8 phased)
+TILE_CASES = [(0, 4), (1, 4), (2, 4), (3, 4), (3, 16), (4, 4)]   # (tile cfg, main-loop variant: 4 single barrier, 8 phased)
 
 
 @pytest.fixture
@@ -423,7 +423,7 @@ def forced_tile(hip):
         hip.debug_set_variant(variant)
     yield force
     hip.debug_set_tile(-1)
-    hip.debug_set_variant(4)
+    hip.debug_set_variant(0)
     hip.debug_set_group(0)
 
 
@@ -431,7 +431,7 @@ def _check_tile(hip, cfg, variant):
     code = hip.debug_last_tile()
     assert code % 100 == cfg, f"forced tile {cfg} but the launch used {code}"
     if cfg == 3:
-        assert code // 100 == {8: 1}.get(variant, 0), f"variant {variant} but tile code {code}"
+        assert code // 100 == {16: 2}.get(variant, 0), f"variant {variant} but tile code {code}"
 
 
 @pytest.mark.parametrize("cfg,variant", TILE_CASES)

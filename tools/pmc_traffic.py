@@ -39,7 +39,8 @@ def main(fetch_csv, write_csv):
             continue
         detail[fam] = {"launches": n, "fetch_kib_raw": f[fam][1], "write_kib_raw": w[fam][1],
                        "bytes_per_launch": (2.0 * f[fam][1] + w[fam][1]) * 1024.0 / n}
-    res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1` (2 forwards, ViT-L bs=32); "
+    res = {"collected": os.environ.get("ADA_COLLECTED", "unstamped"),
+           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1` (2 forwards, ViT-L bs=32); "
                    "KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B); WRITE_SIZE uncalibrated; "
                    "L2-fabric requests, Infinity-Cache hits included.  Algorithmic bytes per igemm launch (operands + outputs once) average "
                    "~0.5 GB: the excess is the weight matrix re-streamed per XCD per tile round (W > 4 MiB L2) and the 9x tap re-read of the "

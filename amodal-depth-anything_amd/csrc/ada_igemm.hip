@@ -410,6 +410,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             const bool more = kt + 1 < nk;
             long aoff = 0, boff = 0;
             if (more) slab_offsets(kt + 1, aoff, boff);
+            // (Spreading the 8 copies of a wave over the MFMAs of "its" k half -- two behind every 8 MFMAs, order pinned with sched_barrier, the
+            // thing that was worth 20 % in the 4-wave loop -- makes THIS loop slower: fc1 +10 %, fc2 +14 %, 8192^3 +20 %; the partner wave on the
+            // SIMD already covers a burst, and the pins cost the compiler its own schedule.  profiles/r03_i_gemm_4wave_asm_loop.txt)
             if (more && !late) stage_part(cur ^ 1, aoff, boff, -1);
             const char* sbase = smem + cur * STAGE_BYTES;
             const int l15 = lane & 15, q4 = lane >> 4;
@@ -427,13 +430,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
 #pragma unroll
                     for (int b2 = 0; b2 < 2; ++b2) bf[j][b2] = *(const opx8*)(sbase + b16_off + (j * 32 + b2 * 16) * RB + coff);
 #pragma unroll
-                for (int i = 0; i < TI; ++i)
+                for (int i = 0; i < TI; ++i) {
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
 #pragma unroll
                         for (int a = 0; a < 2; ++a)
 #pragma unroll
                             for (int b2 = 0; b2 < 2; ++b2) acc[i][j][2 * a + b2] = mfma16(af[i][a], bf[j][b2], acc[i][j][2 * a + b2]);
+                }
                 if (s == 0) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (more && late) stage_part(cur ^ 1, aoff, boff, -1);

@@ -34,7 +34,17 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(72, 20261002), ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}x{c[3]}-{c[4]}-t{c[5]}")
+def _asm_loop_cases(n, seed):
+    """Forced 256x256 tile + the hand-scheduled 4-wave main loop (odd case index selects it below) on the same random shapes, plus long k-loops."""
+    out = []
+    for k, (_, M, N, K, epi, _, pad_a, pad_o) in enumerate(_cases(n, seed)):
+        if k % 6 == 0:
+            K = 64 * (129 + k)      # > 128 k-tiles: also what the heuristic itself sends to this loop
+        out.append((2 * k + 1, M, N, K, epi, 3, pad_a, pad_o))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases(72, 20261002) + _asm_loop_cases(24, 31337), ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}x{c[3]}-{c[4]}-t{c[5]}")
 def test_igemm_random_shapes(hip, case):
     i, M, N, K, epi, tile, pad_a, pad_o = case
     op = hip.operand_dtype()
@@ -58,6 +68,9 @@ def test_igemm_random_shapes(hip, case):
         assert bool((got[M] == GUARD).all()) and (pad_o == 0 or bool((got[:M, N:] == GUARD).all())), "store outside the M x N output"
 
     hip.debug_set_tile(tile)
+    # every other forced 256x256 case runs the hand-scheduled 4-wave main loop (generated assembly): odd / single k-tile counts, ragged M and N,
+    # padded lda -- the shapes its prologue, its out-of-bounds zero-fill copies and its loop exits have to get right
+    hip.debug_set_variant(16 if (tile == 3 and i % 2 == 1) else 0)
     try:
         if epi == "f32":
             hip.igemm(M=M, N=N, K=K, A=A_full, lda=lda, W=W, bias=b, flags=hip.EP_BIAS, out_f32=of, ldo_f32=ldo)
@@ -83,6 +96,7 @@ def test_igemm_random_shapes(hip, case):
             check(oo, lin * g.cpu(), **tol_op)
     finally:
         hip.debug_set_tile(-1)
+        hip.debug_set_variant(0)
 
 
 def _attn_cases(n, seed):

@@ -6,7 +6,7 @@
 
 namespace {
 
-// operand-typed float4 store; split_seg > 0 writes [hi | lo | hi] column segments (split precision, see ada_igemm_args.split_seg)
+// operand-typed float4 store; split_seg > 0 writes [hi | lo] column segments (split precision, see ada_igemm_args.split_seg)
 ADA_DEV void store_op4_split(op_t* row, int c, float4 r, int split_seg) {
     opx4 o;
     o[0] = to_op(r.x); o[1] = to_op(r.y); o[2] = to_op(r.z); o[3] = to_op(r.w);
@@ -15,7 +15,6 @@ ADA_DEV void store_op4_split(op_t* row, int c, float4 r, int split_seg) {
         opx4 l;
         l[0] = to_op(r.x - (float)o[0]); l[1] = to_op(r.y - (float)o[1]); l[2] = to_op(r.z - (float)o[2]); l[3] = to_op(r.w - (float)o[3]);
         ((opx4*)(row + split_seg))[c] = l;
-        ((opx4*)(row + 2 * split_seg))[c] = o;
     }
 }
 
@@ -124,9 +123,9 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const int py = (p / pw) % ph;
     const int b = p / (pw * ph);
     const int kreal = (3 + cg) * 196;
-    // seg == 0: one segment of ld columns.  seg > 0 (split precision): three segments of `seg` columns holding
-    // [hi | lo | hi] with hi = round(x), lo = round(x - hi): paired with weights [w_hi | w_hi | w_lo] one GEMM computes
-    // x_hi w_hi + x_lo w_hi + x_hi w_lo, i.e. the patch embedding to ~fp32 accuracy from fp16 MFMAs.
+    // seg == 0: one segment of ld columns.  seg > 0 (split precision): two segments of `seg` columns holding
+    // [hi | lo] with hi = round(x), lo = round(x - hi): contracted as (hi, lo, hi) against weights [w_hi | w_hi | w_lo] (ada_igemm
+    // a_dup_seg) one GEMM computes x_hi w_hi + x_lo w_hi + x_hi w_lo, i.e. the patch embedding to ~fp32 accuracy from fp16 MFMAs.
     const int width = seg > 0 ? seg : (int)ld;
     for (int pair = threadIdx.x; pair * 2 < width; pair += blockDim.x) {
         const int col = pair * 2;
@@ -159,7 +158,6 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
             lo[0] = to_op(a0 - (float)o[0]);
             lo[1] = to_op(a1 - (float)o[1]);
             *(opx2*)(out + (long)p * ld + seg + col) = lo;
-            *(opx2*)(out + (long)p * ld + 2 * seg + col) = o;
         }
     }
 }
@@ -403,7 +401,7 @@ extern "C" int ada_layernorm_fwd(const float* in, int64_t ld_in, int32_t rows_ou
     p.dMapW = make_fastdiv(map_w > 0 ? map_w : 1);
     p.dMapHW = make_fastdiv(map_h > 0 && map_w > 0 ? map_h * map_w : 1);
     p.relu = relu; p.out_f32 = out_f32; p.ld_f32 = ld_f32;
-    ADA_REQUIRE(split_seg == 0 || (out_op && split_seg >= dim && split_seg % 4 == 0 && ld_op >= 3L * split_seg), ADA_EINVAL, "ada_layernorm_fwd: bad split_seg=%d for dim=%d ld_op=%ld", split_seg, dim, (long)ld_op);
+    ADA_REQUIRE(split_seg == 0 || (out_op && split_seg >= dim && split_seg % 4 == 0 && ld_op >= 2L * split_seg), ADA_EINVAL, "ada_layernorm_fwd: bad split_seg=%d for dim=%d ld_op=%ld", split_seg, dim, (long)ld_op);
     p.split_seg = split_seg;
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows_out + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     return ada_check_launch("ada_layernorm_fwd");
@@ -417,7 +415,7 @@ extern "C" int ada_patchify(const float* x, const float* guide, int32_t batch, i
     ADA_REQUIRE(height % 14 == 0 && width % 14 == 0, ADA_EINVAL, "ada_patchify: %dx%d is not a multiple of the 14-pixel patch", height, width);
     ADA_REQUIRE(ld % 2 == 0 && ld >= (3 + cg) * 196, ADA_EINVAL, "ada_patchify: ld=%ld too small", (long)ld);
     ADA_REQUIRE(split == 0 || split == 1, ADA_EINVAL, "ada_patchify: split must be 0 or 1");
-    ADA_REQUIRE(!split || (ld % 6 == 0 && ld / 3 >= (3 + cg) * 196), ADA_EINVAL, "ada_patchify: split needs ld = 3 * segment, segment >= (3+cg)*196");
+    ADA_REQUIRE(!split || (ld % 4 == 0 && ld / 2 >= (3 + cg) * 196), ADA_EINVAL, "ada_patchify: split needs ld = 2 * segment, segment >= (3+cg)*196");
     ADA_REQUIRE((mean == nullptr) == (inv_std == nullptr), ADA_EINVAL, "ada_patchify: mean and inv_std go together");
     float3 mu = make_float3(0.f, 0.f, 0.f), is = make_float3(1.f, 1.f, 1.f);
     if (mean) {  // host pointers: three floats each
@@ -426,7 +424,7 @@ extern "C" int ada_patchify(const float* x, const float* guide, int32_t batch, i
     }
     const int ph = height / 14, pw = width / 14;
     hipLaunchKernelGGL(patchify_kernel, dim3(batch * ph * pw), dim3(256), 0, (hipStream_t)stream, x, guide, cg, height, width, ph, pw,
-                       mu, is, mean ? 1 : 0, (op_t*)out, (long)ld, split ? (int)(ld / 3) : 0);
+                       mu, is, mean ? 1 : 0, (op_t*)out, (long)ld, split ? (int)(ld / 2) : 0);
     return ada_check_launch("ada_patchify");
 }
 
@@ -453,7 +451,7 @@ extern "C" int ada_bilinear_fwd(const float* in, int64_t ld_in, int32_t batch, i
     p.sx = wo > 1 ? (float)(wi - 1) / (float)(wo - 1) : 0.0f;
     p.add = add; p.ld_add = ld_add; p.out_f32 = out_f32; p.ld_f32 = ld_f32; p.out_op = (op_t*)out_op; p.ld_op = ld_op;
     p.map_op = map_op; p.relu = relu;
-    ADA_REQUIRE(split_seg == 0 || (out_op && split_seg >= channels && split_seg % 4 == 0 && ld_op >= 3L * split_seg), ADA_EINVAL, "ada_bilinear_fwd: bad split_seg=%d for %d channels, ld_op=%ld", split_seg, channels, (long)ld_op);
+    ADA_REQUIRE(split_seg == 0 || (out_op && split_seg >= channels && split_seg % 4 == 0 && ld_op >= 2L * split_seg), ADA_EINVAL, "ada_bilinear_fwd: bad split_seg=%d for %d channels, ld_op=%ld", split_seg, channels, (long)ld_op);
     p.split_seg = split_seg;
     p.dC4 = make_fastdiv(p.c4); p.dWo = make_fastdiv(wo); p.dHo = make_fastdiv(ho);
     ADA_REQUIRE(ho <= 65535 && batch <= 65535, ADA_EUNSUPPORTED, "ada_bilinear_fwd: ho / batch exceed the grid limits");

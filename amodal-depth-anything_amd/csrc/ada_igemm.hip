@@ -61,7 +61,8 @@ struct IgemmDev {
     const float* ln_colsum;   // EP_LNFOLD: per-column sum of the (gain-folded) weights
     float* rowstat_out;       // EP_ROWSTATS: partial (sum, sum of squares) of the fp32 output per row and 64-column group
     int rowstat_groups;       // N / 64
-    int split_seg;   // > 0: the op-typed output is written as [hi | lo | hi] in three column segments of this width (split precision)
+    int split_seg;   // > 0: the op-typed output is written as [hi | lo] in two column segments of this width (split precision)
+    int a_dup_seg;   // > 0: the A operand is a [hi | lo] split tensor contracted as (hi, lo, hi) against [w_hi | w_hi | w_lo] weights
     FastDiv dShC, dShS;
     const float* tail_w;
     float tail_b;
@@ -144,10 +145,10 @@ ADA_DEV opx4 pack4(float4 v) {
     return o;
 }
 
-// Operand-typed stores.  With split_seg > 0 the value is written in split precision, hi = round(v) at column n and again at
-// n + 2 seg, lo = round(v - hi) at n + seg: a following contraction over K = 3 seg against weights packed [w_hi | w_hi | w_lo]
-// evaluates x_hi w_hi + x_lo w_hi + x_hi w_lo, i.e. the product to ~fp32 accuracy on the fp16 matrix cores (used for the DPT head of
-// the unbounded-output models).
+// Operand-typed stores.  With split_seg > 0 the value is written in split precision, hi = round(v) at column n, lo = round(v - hi) at
+// n + seg: a following contraction over the THREE k segments (hi, lo, hi) -- the third re-reads the first, ada_igemm_args.a_dup_seg --
+// against weights packed [w_hi | w_hi | w_lo] evaluates x_hi w_hi + x_lo w_hi + x_hi w_lo, i.e. the product to ~fp32 accuracy on the fp16
+// matrix cores (used for selected contractions of the DPT head and the patch embedding).
 ADA_DEV void store_op4(const IgemmDev& p, op_t* dst, float4 v) {
     const opx4 h = pack4(v);
     *(opx4*)dst = h;
@@ -155,7 +156,6 @@ ADA_DEV void store_op4(const IgemmDev& p, op_t* dst, float4 v) {
         float4 r;
         r.x = v.x - (float)h[0]; r.y = v.y - (float)h[1]; r.z = v.z - (float)h[2]; r.w = v.w - (float)h[3];
         *(opx4*)(dst + p.split_seg) = pack4(r);
-        *(opx4*)(dst + 2 * p.split_seg) = h;
     }
 }
 ADA_DEV void store_op8(const IgemmDev& p, op_t* dst, float4 v0, float4 v1) {
@@ -173,7 +173,6 @@ ADA_DEV void store_op8(const IgemmDev& p, op_t* dst, float4 v0, float4 v1) {
         l[0] = a[0]; l[1] = a[1]; l[2] = a[2]; l[3] = a[3];
         l[4] = b[0]; l[5] = b[1]; l[6] = b[2]; l[7] = b[3];
         *(opx8*)(dst + p.split_seg) = l;
-        *(opx8*)(dst + 2 * p.split_seg) = o;
     }
 }
 
@@ -303,13 +302,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     }
 
     // k-step kt -> element offsets of its A and W slabs (wave-uniform scalars)
-    const int cps = (int)(p.lda / BK);  // k-steps per conv tap
+    // a split A operand ([hi | lo] per row / per tap) is contracted as three k segments (hi, lo, hi): segment 2 re-reads segment 0
+    const int sps = p.a_dup_seg / BK;                                   // k-steps per segment (0: plain operand)
+    const int cps = sps > 0 ? 3 * sps : (int)(p.lda / BK);              // k-steps per conv tap
     auto slab_offsets = [&](int kt, long& aoff, long& boff) {
         if (p.a_mode == ADA_A_PLAIN) {
-            aoff = (long)kt * BK;
+            aoff = (long)((sps > 0 && kt >= 2 * sps) ? kt - 2 * sps : kt) * BK;
         } else {
             const int tap = kt / cps;
-            const int kc = kt - tap * cps;
+            int kc = kt - tap * cps;
+            if (sps > 0 && kc >= 2 * sps) kc -= 2 * sps;
             const int dy = tap / 3, dx = tap - dy * 3;
             aoff = ((long)dy * p.Wp + dx) * p.lda + (long)kc * BK;
         }
@@ -966,7 +968,8 @@ static inline double tile_time(long M, long N, int bm, int bn, int occ, double e
 
 // main loop of the 256x256 tile: variant 16 forces the hand-scheduled 4-wave loop, 4 the single-barrier 8-wave loop; 0 (default) picks the
 // 4-wave loop where its main loop outweighs its slower prologue / epilogue (measured: k-loops of >= 128 k-tiles)
-static inline bool use_pipe4(const IgemmDev& d) { return d.variant >= 16 || (d.variant == 0 && d.K >= 8192); }
+// (its scalar A-offset counters assume a monotonic walk: a split operand, whose third k segment re-reads the first, stays on the 8-wave loop)
+static inline bool use_pipe4(const IgemmDev& d) { return d.a_dup_seg == 0 && (d.variant >= 16 || (d.variant == 0 && d.K >= 8192)); }
 
 template <int EPI>
 int launch_epi(IgemmDev& d, hipStream_t s, int force) {
@@ -1034,16 +1037,22 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     ADA_REQUIRE(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->W % 16) == 0, ADA_EINVAL, "ada_igemm: operands must be 16-byte aligned");
     ADA_REQUIRE(a->out_f32 || a->out_op, ADA_EINVAL, "ada_igemm: no output buffer");
     ADA_REQUIRE((long)a->M < (1L << 24), ADA_EUNSUPPORTED, "ada_igemm: M=%d exceeds 2^24 rows", a->M);
+    ADA_REQUIRE(a->a_dup_seg >= 0 && a->a_dup_seg % 64 == 0, ADA_EINVAL, "ada_igemm: a_dup_seg=%d must be a non-negative multiple of 64", a->a_dup_seg);
+    if (a->a_dup_seg > 0) {
+        const long taps = a->a_mode == ADA_A_CONV3 ? 9 : 1;
+        ADA_REQUIRE((long)a->K == 3L * taps * a->a_dup_seg && a->lda >= 2L * a->a_dup_seg, ADA_EINVAL,
+                    "ada_igemm: a split A operand needs K == %ld * a_dup_seg and lda >= 2 * a_dup_seg (K=%d a_dup_seg=%d lda=%ld)", 3 * taps, a->K, a->a_dup_seg, (long)a->lda);
+    }
     if (a->a_mode == ADA_A_CONV3) {
         ADA_REQUIRE(a->lda % 64 == 0, ADA_EINVAL, "ada_igemm: CONV3 needs lda %% 64 == 0 (got %ld)", (long)a->lda);
-        ADA_REQUIRE(a->K == 9 * a->lda, ADA_EINVAL, "ada_igemm: CONV3 needs K == 9*lda (K=%d lda=%ld)", a->K, (long)a->lda);
+        ADA_REQUIRE(a->a_dup_seg > 0 || a->K == 9 * a->lda, ADA_EINVAL, "ada_igemm: CONV3 needs K == 9*lda (K=%d lda=%ld)", a->K, (long)a->lda);
         ADA_REQUIRE(a->Ho > 0 && a->Wo > 0 && (a->stride == 1 || a->stride == 2), ADA_EINVAL, "ada_igemm: bad conv geometry");
         ADA_REQUIRE(a->Hp >= (a->Ho - 1) * a->stride + 3 && a->Wp >= (a->Wo - 1) * a->stride + 3, ADA_EINVAL,
                     "ada_igemm: padded input %dx%d too small for output %dx%d stride %d", a->Hp, a->Wp, a->Ho, a->Wo, a->stride);
         ADA_REQUIRE(a->M % (a->Ho * a->Wo) == 0, ADA_EINVAL, "ada_igemm: M must be batch*Ho*Wo");
     } else {
         ADA_REQUIRE(a->a_mode == ADA_A_PLAIN, ADA_EINVAL, "ada_igemm: unknown a_mode %d", a->a_mode);
-        ADA_REQUIRE(a->lda >= a->K, ADA_EINVAL, "ada_igemm: lda=%ld < K=%d", (long)a->lda, a->K);
+        ADA_REQUIRE(a->a_dup_seg > 0 || a->lda >= a->K, ADA_EINVAL, "ada_igemm: lda=%ld < K=%d", (long)a->lda, a->K);
     }
     const int f = a->flags;
     ADA_REQUIRE(!(f & ADA_EP_BIAS) || a->bias, ADA_EINVAL, "ada_igemm: EP_BIAS without bias");
@@ -1093,7 +1102,7 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     if (a->split_seg != 0) {
         ADA_REQUIRE(a->out_op && a->split_seg > 0 && a->split_seg % 8 == 0 && !swiglu, ADA_EINVAL, "ada_igemm: split_seg needs out_op, a positive multiple of 8, no SwiGLU");
         const int cols = shuffle ? a->shuffle_c : a->N;
-        ADA_REQUIRE(cols <= a->split_seg && a->ldo_op >= 3L * a->split_seg, ADA_EINVAL, "ada_igemm: split_seg=%d too small for %d columns / ldo_op=%ld", a->split_seg, cols, (long)a->ldo_op);
+        ADA_REQUIRE(cols <= a->split_seg && a->ldo_op >= 2L * a->split_seg, ADA_EINVAL, "ada_igemm: split_seg=%d too small for %d columns / ldo_op=%ld", a->split_seg, cols, (long)a->ldo_op);
     }
     if ((a->out_f32 && a->map_f32 == ADA_MAP_TOKEN) || (a->out_op && a->map_op == ADA_MAP_TOKEN)) {
         ADA_REQUIRE(a->map_h > 0 && a->M % a->map_h == 0, ADA_EINVAL, "ada_igemm: TOKEN map needs map_h = patches per image");
@@ -1119,6 +1128,7 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.dMapHW = make_fastdiv(token ? a->map_h : (a->map_h > 0 && a->map_w > 0 ? a->map_h * a->map_w : 1));
     d.shuffle_s = a->shuffle_s; d.shuffle_c = a->shuffle_c;
     d.split_seg = a->split_seg;
+    d.a_dup_seg = a->a_dup_seg;
     d.ln_stats = a->ln_stats; d.ln_colsum = a->ln_colsum;
     d.rowstat_out = a->rowstat_out; d.rowstat_groups = a->N / 64;
     d.dShC = make_fastdiv(a->shuffle_c > 0 ? a->shuffle_c : 1);

@@ -52,7 +52,7 @@ class IgemmArgs(ctypes.Structure):
         ("out_op", c_void_p), ("ldo_op", c_int64), ("map_op", c_int32),
         ("map_h", c_int32), ("map_w", c_int32), ("shuffle_s", c_int32), ("shuffle_c", c_int32),
         ("tail_w", c_void_p), ("tail_b", c_float), ("tail_act", c_int32),
-        ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("rowstat_out", c_void_p), ("split_seg", c_int32),
+        ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("rowstat_out", c_void_p), ("split_seg", c_int32), ("a_dup_seg", c_int32),
     ]
 
 
@@ -206,7 +206,7 @@ def set_timer(t: Optional[KernelTimer]):
 def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=None, gamma=None, res=None, ldr=0,
           res_row_mod=0, res_row_off=0, flags=0, out_f32=None, ldo_f32=0, map_f32=MAP_PLAIN, out_op=None, ldo_op=0,
           map_op=MAP_PLAIN, map_h=0, map_w=0, shuffle_s=0, shuffle_c=0, tail_w=None, tail_b=0.0, tail_act=ACT_NONE, split_seg=0,
-          ln_stats=None, ln_colsum=None, rowstat_out=None):
+          ln_stats=None, ln_colsum=None, rowstat_out=None, a_dup_seg=0):
     op = operand_dtype()
     a = IgemmArgs()
     a.M, a.N, a.K, a.a_mode = M, N, K, a_mode
@@ -223,6 +223,7 @@ def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=Non
     a.map_h, a.map_w, a.shuffle_s, a.shuffle_c = map_h, map_w, shuffle_s, shuffle_c
     a.tail_w, a.tail_b, a.tail_act = _opt(tail_w, "tail_w", torch.float32), tail_b, tail_act
     a.split_seg = split_seg
+    a.a_dup_seg = a_dup_seg
     a.ln_stats, a.ln_colsum = _opt(ln_stats, "ln_stats", torch.float32), _opt(ln_colsum, "ln_colsum", torch.float32)
     a.rowstat_out = _opt(rowstat_out, "rowstat_out", torch.float32)
     if _timer is not None and _timer.active:

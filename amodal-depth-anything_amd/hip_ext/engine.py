@@ -96,11 +96,11 @@ class PackedWeights:
         cfg = VIT[encoder]
         D = cfg["dim"]
         self.encoder, self.guided, self.amodal_head = encoder, guided, amodal_head
-        # split_head: every contraction of the DPT head runs in split precision -- activations are stored as [hi | lo | hi]
-        # column segments by the producing kernel (split_seg) and weights are packed [w_hi | w_hi | w_lo], so one fp16 GEMM over
-        # 3x the K evaluates x_hi w_hi + x_lo w_hi + x_hi w_lo (~fp32 operand accuracy).  Used where the head's operand rounding
+        # split_head: contractions of the DPT head run in split precision -- activations are stored as [hi | lo] column segments by the
+        # producing kernel (split_seg), weights are packed [w_hi | w_hi | w_lo], and one fp16 GEMM over the three k segments (hi, lo, hi:
+        # the third re-reads the first, ada_igemm a_dup_seg) evaluates x_hi w_hi + x_lo w_hi + x_hi w_lo (~fp32 operand accuracy).  Used where the head's operand rounding
         # is what limits parity: the unbounded-output models (raw ReLU / 'ssi' heads) and ViT-S.
-        # The choice is PER LAYER GROUP (HEAD_GROUPS): a contraction of a split group reads a [hi | lo | hi] activation (its producer is
+        # The choice is PER LAYER GROUP (HEAD_GROUPS): a contraction of a split group reads a [hi | lo] activation (its producer is
         # told through split_seg) and [w_hi | w_hi | w_lo] weights; the others run at 1x the MACs.  True = every group.
         if split_head is True:
             split_head = HEAD_GROUPS
@@ -157,7 +157,8 @@ class PackedWeights:
         w_lo = (w_pad - w_hi.float()).to(op)
         self.pe_w = torch.cat([w_hi, w_hi, w_lo], dim=1).contiguous()
         self.pe_b = b_pe.contiguous()
-        self.pe_k = self.pe_w.shape[1]
+        self.pe_k = self.pe_w.shape[1]      # K of the embedding GEMM: three segments (hi, lo, hi) of pe_seg
+        self.pe_seg = seg
         self.pe_k_alg = k_real
         self.cls = f32(p + "cls_token").reshape(D)
         self.pos_native = f32(p + "pos_embed")  # [1, 1 + 37*37, D]
@@ -311,15 +312,15 @@ class Workspace:
         T, P = B * N, B * Np
         Fch = pw_.features
         Fp = _r64(Fch)
-        def mm(group):     # an op-typed head tensor holds [hi | lo | hi] segments iff the contraction that READS it is in a split group
-            return 3 if group in pw_.split else 1
+        def mm(group):     # an op-typed head tensor holds [hi | lo] segments iff the contraction that READS it is in a split group
+            return 2 if group in pw_.split else 1
         m = mm("proj")
         first = "ip" if pw_.amodal_head else "rn"     # the contraction family that reads the reassembled maps L[i]
 
         def z(*shape, dtype=op):
             return torch.zeros(*shape, dtype=dtype, device=device)
 
-        self.a_pe = z(P, pw_.pe_k)
+        self.a_pe = z(P, 2 * pw_.pe_seg)     # split-precision patches: [hi | lo]
         self.x = z(T, D, dtype=torch.float32)
         self.y = z(T, D)     # LayerNorm output; with folded LayerNorms: the operand-typed copy of the residual stream itself
         if pw_.fold_ln:
@@ -349,17 +350,30 @@ class Workspace:
         self.rnx = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
         self.rnr = [z(B, g[0] + 2, g[1] + 2, mm(f"rcu{i}") * Fp) for i, g in enumerate(self.grid)]
         self.tmpa = [z(B, g[0] + 2, g[1] + 2, mm(f"rcu{i}") * Fp) for i, g in enumerate(self.grid)]
-        self.r = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
-        self.s = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
+        # fp32 side buffers whose lifetimes do not overlap share storage (plain row buffers only: the zero-bordered operand tensors keep their own,
+        # their borders are written once).  Launch order of _head: ip conv -> LN (ipf dead) ... rn convs ... per level i = 3..0:
+        # RCU2(i) [reads s[i]] -> out_conv [writes zf[i]] -> RCU1(i-1) [reads rnx[i-1], writes r[i-1]] -> resize [reads zf[i], r[i-1], writes s[i-1]];
+        # then resize zf[0] -> p1, output_conv1 [writes oc1].  So: zf[i] lives in rnx[i] (dead since RCU1(i) / RCU2(3)), r[i] in ipf[i] where that is
+        # large enough, and oc1 (4 x the pixels, half the channels = 2 x one level-0 buffer) in the level-0 pair (r[0], s[0]).
+        rows = [B * g[0] * g[1] for g in self.grid]
+        lvl0 = z(2 * rows[0] * Fch, dtype=torch.float32)
+        self.r = [lvl0[:rows[0] * Fch].view(rows[0], Fch)]
+        self.s = [lvl0[rows[0] * Fch:].view(rows[0], Fch)]
+        for i in range(1, 4):
+            if pw_.amodal_head and oc[i] >= Fch:
+                self.r.append(self.ipf[i].view(-1)[:rows[i] * Fch].view(rows[i], Fch))
+            else:
+                self.r.append(z(rows[i], Fch, dtype=torch.float32))
+            self.s.append(z(rows[i], Fch, dtype=torch.float32))
         self.sr = [z(B, g[0] + 2, g[1] + 2, mm(f"rcu{i}") * Fp) for i, g in enumerate(self.grid)]
         self.u = [z(B * g[0] * g[1], mm(f"out{i}") * Fp) for i, g in enumerate(self.grid)]
-        self.zf = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
+        self.zf = self.rnx
         g0 = self.grid[0]
         self.g296 = (2 * g0[0], 2 * g0[1])
         self.p1 = z(B, self.g296[0] + 2, self.g296[1] + 2, mm("oc1") * Fp)
         half = Fch // 2
         self.half, self.halfp = half, _r64(half)
-        self.oc1 = z(B * self.g296[0] * self.g296[1], half, dtype=torch.float32)
+        self.oc1 = lvl0.view(B * self.g296[0] * self.g296[1], half)
         # fused tail (ada_dpt_tail_fwd): resize + output_conv2 in one kernel, the up-sampled map is never materialised.  Needs the
         # single-precision head and a channel count that is already a multiple of 64 (ViT-B / ViT-L heads)
         self.fused_tail = ("oc2" not in pw_.split) and half == self.halfp and FUSED_TAIL
@@ -455,10 +469,24 @@ class DepthEngine:
 
     # ---- small helpers over igemm ---------------------------------------------------------
     @staticmethod
-    def _conv3(src_pad, w, M, N, grid, stride=1, cin=None, **kw):
+    def _kdup(a_width: int, w: torch.Tensor, taps: int = 1) -> dict:
+        """K / lda / a_dup_seg of a contraction whose A rows are ``a_width`` wide and whose packed weights are ``w`` [N, K]: either a plain
+        operand (K == taps * a_width) or a split one -- [hi | lo] activations against [w_hi | w_hi | w_lo] weights, 2 K == 3 taps a_width,
+        the third k segment re-reading the first (ada_igemm a_dup_seg)."""
+        K = int(w.shape[1])
+        if K == taps * a_width:
+            return dict(K=K, lda=a_width, a_dup_seg=0)
+        if 2 * K == 3 * taps * a_width:
+            return dict(K=K, lda=a_width, a_dup_seg=a_width // 2)
+        raise HipExtError(f"packed weights with K={K} do not fit an operand of width {a_width} ({taps} tap(s))")
+
+    @classmethod
+    def _conv3(cls, src_pad, w, M, N, grid, stride=1, cin=None, **kw):
+        """3x3 conv over a zero-bordered NHWC tensor (plain or split input, see _kdup)."""
         B, Hp, Wp, Cp = src_pad.shape
-        k_igemm(M=M, N=N, K=9 * Cp, k_alg=9 * (cin or Cp), A=src_pad, lda=Cp, W=w, a_mode=A_CONV3,
-                conv=(grid[0], grid[1], Hp, Wp, stride), **kw)
+        kd = cls._kdup(Cp, w, taps=9)
+        k_igemm(M=M, N=N, k_alg=9 * (cin or (kd["a_dup_seg"] or Cp)), A=src_pad, W=w, a_mode=A_CONV3,
+                conv=(grid[0], grid[1], Hp, Wp, stride), **kd, **kw)
 
     def forward(self, x: torch.Tensor, guide: Optional[torch.Tensor], normalise: Optional[bool] = None) -> torch.Tensor:
         """One forward.  ``normalise`` overrides the engine's default for the fused ImageNet normalisation of the input (the
@@ -521,9 +549,9 @@ class DepthEngine:
         norm = self.normalise_input if norm is None else norm
         mean = (0.485, 0.456, 0.406) if norm else None
         inv_std = (1 / 0.229, 1 / 0.224, 1 / 0.225) if norm else None
-        k_patchify(x, guide if w.guided else None, B, w.guide_channels, H, W, mean, inv_std, ws.a_pe, w.pe_k, split=True)
+        k_patchify(x, guide if w.guided else None, B, w.guide_channels, H, W, mean, inv_std, ws.a_pe, 2 * w.pe_seg, split=True)
         pos = w.pos_embed(ph, pw)
-        k_igemm(M=P, N=D, K=w.pe_k, k_alg=(3 + w.guide_channels) * 196, A=ws.a_pe, lda=w.pe_k, W=w.pe_w, bias=w.pe_b, res=pos, ldr=D, res_row_mod=Np, res_row_off=1,
+        k_igemm(M=P, N=D, K=w.pe_k, k_alg=(3 + w.guide_channels) * 196, A=ws.a_pe, lda=2 * w.pe_seg, a_dup_seg=w.pe_seg, W=w.pe_w, bias=w.pe_b, res=pos, ldr=D, res_row_mod=Np, res_row_off=1,
                 flags=EP_BIAS | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, map_f32=MAP_TOKEN, map_h=Np)
         k_write_cls(ws.x, B, N, D, w.cls, pos)
 
@@ -592,7 +620,7 @@ class DepthEngine:
         ocp, Fp = ws.ocp, ws.Fp
         first = "ip" if w.amodal_head else "rn"     # the family of the contraction that reads the reassembled maps L[i]
 
-        def S(group, seg):   # split_seg argument of a producer whose CONSUMER (a contraction of `group`) reads [hi | lo | hi] segments of width seg
+        def S(group, seg):   # split_seg argument of a producer whose CONSUMER (a contraction of `group`) reads [hi | lo] segments of width seg
             return seg if group in w.split else 0
 
         taps_in = ws.taps
@@ -600,22 +628,22 @@ class DepthEngine:
             KDr = ws.taps[0].shape[1]
             Np = ph * pw
             for i in range(4):
-                k_igemm(M=B, N=D, K=KDr, k_alg=D, A=ws.cls_op[i], lda=KDr, W=w.ro_wc[i], bias=w.ro_b[i], flags=EP_BIAS, out_f32=ws.cls_bias[i], ldo_f32=D)
+                k_igemm(M=B, N=D, k_alg=D, A=ws.cls_op[i], W=w.ro_wc[i], bias=w.ro_b[i], flags=EP_BIAS, out_f32=ws.cls_bias[i], ldo_f32=D, **self._kdup(KDr, w.ro_wc[i]))
                 for b in range(B):
-                    k_igemm(M=Np, N=D, K=KDr, k_alg=D, A=ws.taps[i][b * Np:(b + 1) * Np], lda=KDr, W=w.ro_wx[i], bias=ws.cls_bias[i][b],
+                    k_igemm(M=Np, N=D, k_alg=D, A=ws.taps[i][b * Np:(b + 1) * Np], W=w.ro_wx[i], bias=ws.cls_bias[i][b], **self._kdup(KDr, w.ro_wx[i]),
                             flags=EP_BIAS | EP_GELU, out_op=ws.taps_ro[i][b * Np:(b + 1) * Np], ldo_op=ws.taps_ro[i].shape[1], split_seg=S("proj", D))
             taps_in = ws.taps_ro
         # ---- reassemble: 1x1 project + resize (dpt.py:171-173) -> zero-bordered NHWC operand tensors -----
         KD = ws.taps[0].shape[1]
-        k_igemm(M=P, N=oc[0], K=KD, k_alg=D, A=taps_in[0], lda=KD, W=w.proj_w[0], bias=w.proj_b[0], flags=EP_BIAS, out_op=ws.t0, ldo_op=ws.t0.shape[1], split_seg=S("rs0", ocp[0]))
-        k_igemm(M=P, N=16 * oc[0], K=ws.t0.shape[1], k_alg=oc[0], A=ws.t0, lda=ws.t0.shape[1], W=w.rs0_w, bias=w.rs0_b, flags=EP_BIAS,
+        k_igemm(M=P, N=oc[0], k_alg=D, A=taps_in[0], W=w.proj_w[0], **self._kdup(KD, w.proj_w[0]), bias=w.proj_b[0], flags=EP_BIAS, out_op=ws.t0, ldo_op=ws.t0.shape[1], split_seg=S("rs0", ocp[0]))
+        k_igemm(M=P, N=16 * oc[0], k_alg=oc[0], A=ws.t0, W=w.rs0_w, bias=w.rs0_b, flags=EP_BIAS, **self._kdup(ws.t0.shape[1], w.rs0_w),
                 out_op=ws.L[0], ldo_op=ws.L[0].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=4, shuffle_c=oc[0], split_seg=S(first + "0", ocp[0]))
-        k_igemm(M=P, N=oc[1], K=KD, k_alg=D, A=taps_in[1], lda=KD, W=w.proj_w[1], bias=w.proj_b[1], flags=EP_BIAS, out_op=ws.t1, ldo_op=ws.t1.shape[1], split_seg=S("rs1", ocp[1]))
-        k_igemm(M=P, N=4 * oc[1], K=ws.t1.shape[1], k_alg=oc[1], A=ws.t1, lda=ws.t1.shape[1], W=w.rs1_w, bias=w.rs1_b, flags=EP_BIAS,
+        k_igemm(M=P, N=oc[1], k_alg=D, A=taps_in[1], W=w.proj_w[1], **self._kdup(KD, w.proj_w[1]), bias=w.proj_b[1], flags=EP_BIAS, out_op=ws.t1, ldo_op=ws.t1.shape[1], split_seg=S("rs1", ocp[1]))
+        k_igemm(M=P, N=4 * oc[1], k_alg=oc[1], A=ws.t1, W=w.rs1_w, bias=w.rs1_b, flags=EP_BIAS, **self._kdup(ws.t1.shape[1], w.rs1_w),
                 out_op=ws.L[1], ldo_op=ws.L[1].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=2, shuffle_c=oc[1], split_seg=S(first + "1", ocp[1]))
-        k_igemm(M=P, N=oc[2], K=KD, k_alg=D, A=taps_in[2], lda=KD, W=w.proj_w[2], bias=w.proj_b[2], flags=EP_BIAS,
+        k_igemm(M=P, N=oc[2], k_alg=D, A=taps_in[2], W=w.proj_w[2], **self._kdup(KD, w.proj_w[2]), bias=w.proj_b[2], flags=EP_BIAS,
                 out_op=ws.L[2], ldo_op=ws.L[2].shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S(first + "2", ocp[2]))
-        k_igemm(M=P, N=oc[3], K=KD, k_alg=D, A=taps_in[3], lda=KD, W=w.proj_w[3], bias=w.proj_b[3], flags=EP_BIAS,
+        k_igemm(M=P, N=oc[3], k_alg=D, A=taps_in[3], W=w.proj_w[3], **self._kdup(KD, w.proj_w[3]), bias=w.proj_b[3], flags=EP_BIAS,
                 out_op=ws.pre3, ldo_op=ws.pre3.shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S("rs3", ocp[3]))
         self._conv3(ws.pre3, w.rs3_w, rows[3], oc[3], grid[3], stride=2, cin=oc[3], bias=w.rs3_b, flags=EP_BIAS,
                     out_op=ws.L[3], ldo_op=ws.L[3].shape[3], map_op=MAP_PAD, map_h=grid[3][0], map_w=grid[3][1], split_seg=S(first + "3", ocp[3]))
@@ -648,7 +676,7 @@ class DepthEngine:
         for i in (3, 2, 1, 0):
             fw = w.fuse[i]
             rcu(i, fw, 2, s_pad, s_f32, out_op=ws.u[i], ldo_op=ws.u[i].shape[1], split_seg=S(f"out{i}", Fp))
-            k_igemm(M=rows[i], N=Fch, K=ws.u[i].shape[1], k_alg=Fch, A=ws.u[i], lda=ws.u[i].shape[1], W=fw["out_w"], bias=fw["out_b"], flags=EP_BIAS,
+            k_igemm(M=rows[i], N=Fch, k_alg=Fch, A=ws.u[i], W=fw["out_w"], bias=fw["out_b"], flags=EP_BIAS, **self._kdup(ws.u[i].shape[1], fw["out_w"]),
                     out_f32=ws.zf[i], ldo_f32=Fch)
             if i > 0:
                 j = i - 1

@@ -131,8 +131,12 @@ typedef struct ada_igemm_args {
     const float* ln_stats;  /* LNFOLD: fp32 [M, 2] = (mean, rstd) per row (ada_rowstats_finalize) */
     const float* ln_colsum; /* LNFOLD: fp32 [N], sum over k of the operand-typed, gain-folded weights W'[n, k] */
     float* rowstat_out;     /* ROWSTATS: fp32 [M, N/64, 2], (sum, sum of squares) of the fp32 result over each 64-column group */
-    int32_t split_seg;      /* > 0: split-precision op output -- out_op receives [hi | lo | hi] in three column segments of
+    int32_t split_seg;      /* > 0: split-precision op output -- out_op receives [hi | lo] in two column segments of
                                split_seg elements (hi = round(v), lo = round(v - hi)); 0 = plain */
+    int32_t a_dup_seg;      /* > 0: the A operand is such a split tensor: [hi | lo] segments of a_dup_seg elements per row (per tap of a
+                               3x3 conv) and the contraction runs over THREE segments (hi, lo, hi -- the third re-reads the first) against
+                               weights packed [w_hi | w_hi | w_lo]: x_hi w_hi + x_lo w_hi + x_hi w_lo.  K = 3 * a_dup_seg (x 9 for CONV3),
+                               lda >= 2 * a_dup_seg.  0 = plain operand */
 } ada_igemm_args;
 
 int ada_igemm(const ada_igemm_args* args, void* stream);
@@ -164,7 +168,7 @@ int ada_attention_fwd(const void* qkv, void* out, int32_t batch, int32_t n_token
  * `skip` rows of each group (drops the cls token: dinov2.py:339-340); output rows are compacted.
  * Output (either may be NULL): op-typed with row map (PLAIN or PAD) and optional ReLU
  * (DA2/dpt.py:158), and/or fp32 plain.  split_seg > 0 writes the op-typed output in split precision
- * ([hi | lo | hi] column segments, see ada_igemm_args.split_seg).
+ * ([hi | lo] column segments, see ada_igemm_args.split_seg).
  * ---------------------------------------------------------------------------------------- */
 int ada_layernorm_fwd(const float* in, int64_t ld_in, int32_t rows_out, int32_t dim,
                       int32_t group_in, int32_t skip,
@@ -181,7 +185,7 @@ int ada_layernorm_fwd(const float* in, int64_t ld_in, int32_t rows_out, int32_t 
  * out: op-typed [B*(H/14)*(W/14), ld] with column (c*196 + dy*14 + dx), c over RGB then guide
  * channels; columns >= (3+Cg)*196 are written as zero.  mean/inv_std: [3] fp32 HOST pointers or NULL (raw
  * model, already normalised by the caller: infer.py:19).
- * split = 1 (split-precision embed): ld = 3 * segment and the row holds [hi | lo | hi], hi = round_op(x),
+ * split = 1 (split-precision embed): ld = 2 * segment and the row holds [hi | lo], hi = round_op(x),
  * lo = round_op(x - hi); with weights packed as [w_hi | w_hi | w_lo] the following GEMM evaluates the patch
  * embedding to ~fp32 accuracy on the fp16 matrix cores (3x the MACs of a layer that is 0.2 % of the model).
  * ---------------------------------------------------------------------------------------- */

@@ -379,18 +379,18 @@ def test_pipeline_glue_kernels(hip):
 
 
 def test_patchify_split_precision(hip):
-    """[hi | lo | hi] layout: hi + lo reproduces the fp32 pixel to ~2^-22, and a GEMM against [w_hi | w_hi | w_lo] matches fp32."""
+    """[hi | lo] layout: hi + lo reproduces the fp32 pixel to ~2^-22, and a GEMM over the k segments (hi, lo, hi) against [w_hi | w_hi | w_lo]
+    (a_dup_seg: the third segment re-reads the first) matches fp32."""
     op = _op(hip)
     B, H, W, cg = 1, 28, 42, 2
     x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(60))
     g = torch.rand(B, cg, H, W, generator=torch.Generator().manual_seed(61)) * 2 - 1
     K = (3 + cg) * 196
     seg = (K + 63) // 64 * 64
-    out = torch.zeros(B * 6, 3 * seg, dtype=op, device=DEV)
-    hip.patchify(x.to(DEV), g.to(DEV), B, cg, H, W, None, None, out, 3 * seg, split=True)
+    out = torch.zeros(B * 6, 2 * seg, dtype=op, device=DEV)
+    hip.patchify(x.to(DEV), g.to(DEV), B, cg, H, W, None, None, out, 2 * seg, split=True)
     ref = F.unfold(torch.cat([x, g], 1), 14, stride=14).transpose(1, 2).reshape(B * 6, K)
     o = out.float().cpu()
-    assert torch.equal(o[:, :K], o[:, 2 * seg:2 * seg + K])
     rec = o[:, :K] + o[:, seg:seg + K]
     tol = 1e-6 if op == torch.float16 else 1e-4
     assert float((rec - ref).abs().max()) < tol
@@ -401,7 +401,7 @@ def test_patchify_split_precision(hip):
     w_lo = (wp - w_hi.float()).to(op)
     Wcat = torch.cat([w_hi, w_hi, w_lo], 1).contiguous().to(DEV)
     y = torch.zeros(B * 6, 64, device=DEV)
-    hip.igemm(M=B * 6, N=64, K=3 * seg, A=out, lda=3 * seg, W=Wcat, out_f32=y, ldo_f32=64)
+    hip.igemm(M=B * 6, N=64, K=3 * seg, A=out, lda=2 * seg, a_dup_seg=seg, W=Wcat, out_f32=y, ldo_f32=64)
     err = (y.cpu() - ref @ w.T).abs().max()
     assert float(err) < (2e-5 if op == torch.float16 else 2e-3), float(err)
 
@@ -610,7 +610,7 @@ def test_attention_last_batch_does_not_read_past_the_buffer(hip):
 
 
 # =====================================================================================================================
-# Split-precision operand stores (split_seg): [hi | lo | hi] column segments + weights packed [w_hi | w_hi | w_lo]
+# Split-precision operand stores (split_seg): [hi | lo] column segments, contracted as (hi, lo, hi) (a_dup_seg) with weights [w_hi | w_hi | w_lo]
 # =====================================================================================================================
 def _triple_w(w, op):
     hi = w.to(op)
@@ -619,22 +619,22 @@ def _triple_w(w, op):
 
 
 def _check_split(buf, ref, C, seg, op, what, exact=True):
-    """buf [..., 3*seg] op-typed; ref [..., C] fp32: hi = round(ref), lo = round(ref - hi), third segment == hi, pads zero.
+    """buf [..., 2*seg] op-typed; ref [..., C] fp32: hi = round(ref), lo = round(ref - hi), pads zero.
     exact=False: ref was computed on the host (differs from the device's fp32 value by ulps), so only hi + lo ~ ref is checked."""
     b = buf.float().cpu()
-    hi, lo, hi2 = b[..., :C], b[..., seg:seg + C], b[..., 2 * seg:2 * seg + C]
+    assert b.shape[-1] == 2 * seg
+    hi, lo = b[..., :C], b[..., seg:seg + C]
     want_hi = ref.to(op).float()
     want_lo = (ref - want_hi).to(op).float()
     tol = 1e-2 if op == torch.bfloat16 else 2e-3
     _close(hi, ref, 2e-3, rtol=tol, what=what + " hi")
-    assert torch.equal(hi, hi2), what + ": third segment differs from the first"
     resid = (hi + lo - ref).abs().max() / ref.abs().max()
     lim = (3e-5 if op == torch.bfloat16 else 1e-6) if exact else (1e-4 if op == torch.bfloat16 else 3e-6)
     assert float(resid) < lim, f"{what}: hi + lo misses the fp32 value by {float(resid):.2e} (relative)"
     if exact:
         frac_exact = float(((hi == want_hi) & (lo == want_lo)).float().mean())
         assert frac_exact > 0.99, f"{what}: only {frac_exact:.3f} of the (hi, lo) pairs are the roundings of the fp32 value"
-    for a, z in ((C, seg), (seg + C, 2 * seg), (2 * seg + C, 3 * seg)):
+    for a, z in ((C, seg), (seg + C, 2 * seg)):
         if z > a:
             assert float(b[..., a:z].abs().max()) == 0.0, what + ": pad columns written"
 
@@ -645,8 +645,8 @@ def test_split_store_bilinear_layernorm_and_gemm_accuracy(hip):
     seg = 64
     x = _rand(B * H * W_, C, seed=301) * 3
     # identity resample (hi == ho, wi == wo) = a split cast
-    buf = torch.zeros(B * H * W_, 3 * seg, dtype=op, device=DEV)
-    hip.bilinear(x.to(DEV), C, B, H, W_, H, W_, C, out_op=buf, ld_op=3 * seg, map_op=hip.MAP_PLAIN, split_seg=seg)
+    buf = torch.zeros(B * H * W_, 2 * seg, dtype=op, device=DEV)
+    hip.bilinear(x.to(DEV), C, B, H, W_, H, W_, C, out_op=buf, ld_op=2 * seg, map_op=hip.MAP_PLAIN, split_seg=seg)
     _check_split(buf, x, C, seg, op, "bilinear split")
     # GEMM over the triple K against triple weights ~ fp32 product
     N = 96
@@ -654,7 +654,7 @@ def test_split_store_bilinear_layernorm_and_gemm_accuracy(hip):
     wp = torch.zeros(N, seg)
     wp[:, :C] = w
     out = torch.zeros(B * H * W_, N, device=DEV)
-    hip.igemm(M=B * H * W_, N=N, K=3 * seg, A=buf, lda=3 * seg, W=_triple_w(wp, op).to(DEV), out_f32=out, ldo_f32=N)
+    hip.igemm(M=B * H * W_, N=N, K=3 * seg, A=buf, lda=2 * seg, a_dup_seg=seg, W=_triple_w(wp, op).to(DEV), out_f32=out, ldo_f32=N)
     ref = x @ w.T
     err = float((out.cpu() - ref).abs().max() / ref.abs().max())
     single = float((x.to(op).float() @ w.to(op).float().T - ref).abs().max() / ref.abs().max())
@@ -663,10 +663,10 @@ def test_split_store_bilinear_layernorm_and_gemm_accuracy(hip):
     # padded NHWC + ReLU through the bilinear kernels (per-pixel and LDS-tiled)
     for Cw, hi_, wi_, ho_, wo_ in ((64, 5, 7, 10, 14), (128, 19, 19, 37, 37)):
         xin = _rand(B, Cw, hi_, wi_, seed=303)
-        o = torch.zeros(B, ho_ + 2, wo_ + 2, 3 * Cw, dtype=op, device=DEV)
+        o = torch.zeros(B, ho_ + 2, wo_ + 2, 2 * Cw, dtype=op, device=DEV)
         of = torch.zeros(B * ho_ * wo_, Cw, device=DEV)
         hip.bilinear(xin.permute(0, 2, 3, 1).reshape(-1, Cw).contiguous().to(DEV), Cw, B, hi_, wi_, ho_, wo_, Cw, out_f32=of, ld_f32=Cw,
-                     out_op=o, ld_op=3 * Cw, map_op=hip.MAP_PAD, relu=True, split_seg=Cw)
+                     out_op=o, ld_op=2 * Cw, map_op=hip.MAP_PAD, relu=True, split_seg=Cw)
         r = F.interpolate(xin, size=(ho_, wo_), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
         _close(of.reshape(B, ho_, wo_, Cw), r, 2e-5, rtol=1e-5, what="bilinear f32")
         _check_split(o[:, 1:-1, 1:-1], of.cpu().reshape(B, ho_, wo_, Cw).clamp_min(0), Cw, Cw, op, f"bilinear pad split C={Cw}")
@@ -677,9 +677,9 @@ def test_split_store_bilinear_layernorm_and_gemm_accuracy(hip):
     D = 96
     xs = _rand(40, D, seed=304)
     wln, bln = _rand(D, seed=305), _rand(D, seed=306)
-    o = torch.zeros(40, 3 * 128, dtype=op, device=DEV)
+    o = torch.zeros(40, 2 * 128, dtype=op, device=DEV)
     of = torch.zeros(40, D, device=DEV)
-    hip.layernorm(xs.to(DEV), D, 40, D, wln.to(DEV), bln.to(DEV), 1e-6, out_op=o, ld_op=3 * 128, out_f32=of, ld_f32=D, split_seg=128)
+    hip.layernorm(xs.to(DEV), D, 40, D, wln.to(DEV), bln.to(DEV), 1e-6, out_op=o, ld_op=2 * 128, out_f32=of, ld_f32=D, split_seg=128)
     _close(of, F.layer_norm(xs, (D,), wln, bln, 1e-6), 2e-5, rtol=1e-5, what="ln f32")
     _check_split(o, of.cpu(), D, 128, op, "layernorm split")
 
@@ -696,26 +696,25 @@ def test_igemm_split_output_plain_pad_shuffle(hip, forced_tile, cfg):
     b = _rand(N, seed=313).to(DEV)
     res = _rand(M, N, seed=314)
     lin = A.float().cpu() @ Wt.float().cpu().T + b.cpu()
-    o = torch.zeros(M, 3 * seg, dtype=op, device=DEV)
-    hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=Wt, bias=b, res=res.to(DEV), ldr=N, flags=hip.EP_BIAS | hip.EP_RESIDUAL, out_op=o, ldo_op=3 * seg, split_seg=seg)
+    o = torch.zeros(M, 2 * seg, dtype=op, device=DEV)
+    hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=Wt, bias=b, res=res.to(DEV), ldr=N, flags=hip.EP_BIAS | hip.EP_RESIDUAL, out_op=o, ldo_op=2 * seg, split_seg=seg)
     _check_split(o, lin + res, N, seg, op, f"igemm split plain+res cfg {cfg}", exact=False)
     o.zero_()
-    hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=Wt, bias=b, flags=hip.EP_BIAS | hip.EP_RELU_OP, out_op=o, ldo_op=3 * seg, split_seg=seg)
+    hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=Wt, bias=b, flags=hip.EP_BIAS | hip.EP_RELU_OP, out_op=o, ldo_op=2 * seg, split_seg=seg)
     _check_split(o, lin.clamp_min(0), N, seg, op, f"igemm split plain relu cfg {cfg}", exact=False)
     # PAD (conv3x3 reading a split input, writing a split output): the whole split-precision conv
     B, C, H, W_ = 2, 64, 13, 17
     x = _rand(B, C, H, W_, seed=315)
     w = _rand(C, C, 3, 3, seed=316) * (9 * C) ** -0.5
-    xin = torch.zeros(B, H + 2, W_ + 2, 3 * C, dtype=op)
+    xin = torch.zeros(B, H + 2, W_ + 2, 2 * C, dtype=op)
     xh = x.permute(0, 2, 3, 1).to(op)
     xin[:, 1:-1, 1:-1, :C] = xh
-    xin[:, 1:-1, 1:-1, C:2 * C] = (x.permute(0, 2, 3, 1) - xh.float()).to(op)
-    xin[:, 1:-1, 1:-1, 2 * C:] = xh
+    xin[:, 1:-1, 1:-1, C:] = (x.permute(0, 2, 3, 1) - xh.float()).to(op)
     wp = _triple_w(w.permute(0, 2, 3, 1).contiguous(), op).reshape(C, 27 * C)
-    o = torch.zeros(B, H + 2, W_ + 2, 3 * C, dtype=op, device=DEV)
+    o = torch.zeros(B, H + 2, W_ + 2, 2 * C, dtype=op, device=DEV)
     of = torch.zeros(B * H * W_, C, device=DEV)
-    hip.igemm(M=B * H * W_, N=C, K=27 * C, A=xin.to(DEV), lda=3 * C, W=wp.to(DEV), a_mode=hip.A_CONV3, conv=(H, W_, H + 2, W_ + 2, 1),
-              flags=hip.EP_RELU_OP, out_f32=of, ldo_f32=C, out_op=o, ldo_op=3 * C, map_op=hip.MAP_PAD, map_h=H, map_w=W_, split_seg=C)
+    hip.igemm(M=B * H * W_, N=C, K=27 * C, A=xin.to(DEV), lda=2 * C, a_dup_seg=C, W=wp.to(DEV), a_mode=hip.A_CONV3, conv=(H, W_, H + 2, W_ + 2, 1),
+              flags=hip.EP_RELU_OP, out_f32=of, ldo_f32=C, out_op=o, ldo_op=2 * C, map_op=hip.MAP_PAD, map_h=H, map_w=W_, split_seg=C)
     ref = F.conv2d(x, w, padding=1).permute(0, 2, 3, 1)
     err = float((of.cpu().reshape(B, H, W_, C) - ref).abs().max() / ref.abs().max())
     assert err < (2e-4 if op == torch.bfloat16 else 3e-6), f"split conv3x3 error {err:.2e}"
@@ -730,8 +729,8 @@ def test_igemm_split_output_plain_pad_shuffle(hip, forced_tile, cfg):
     A2 = xs.permute(0, 2, 3, 1).reshape(-1, Ci).to(op).contiguous()
     Wp = wt.permute(2, 3, 1, 0).reshape(s_ * s_ * Co, Ci).to(op).contiguous()
     segc = 64
-    o = torch.zeros(B, 12, 14, 3 * segc, dtype=op, device=DEV)
-    hip.igemm(M=B * 30, N=s_ * s_ * Co, K=Ci, A=A2.to(DEV), lda=Ci, W=Wp.to(DEV), out_op=o, ldo_op=3 * segc, map_op=hip.MAP_SHUFFLE,
+    o = torch.zeros(B, 12, 14, 2 * segc, dtype=op, device=DEV)
+    hip.igemm(M=B * 30, N=s_ * s_ * Co, K=Ci, A=A2.to(DEV), lda=Ci, W=Wp.to(DEV), out_op=o, ldo_op=2 * segc, map_op=hip.MAP_SHUFFLE,
               map_h=5, map_w=6, shuffle_s=s_, shuffle_c=Co, split_seg=segc)
     ref = F.conv_transpose2d(xs, wt, stride=s_).permute(0, 2, 3, 1)
     _check_split(o[:, 1:-1, 1:-1], ref, Co, segc, op, f"igemm split shuffle cfg {cfg}", exact=False)

@@ -124,7 +124,7 @@ _FOLD_LN_DEFAULT = _os.environ.get("ADA_FOLD_LN", "0") == "1"
 #   ViT-S (64-feature head) and every 'ssi' head             -> every head contraction in split precision (1.8e-3 -> 6.9e-4; cheap models)
 #   raw (ReLU) ViT-G, features 384                           -> only the contractions whose operand rounding shows in the output and that are
 #                                                               cheap: the tail conv, the 1x1 out_convs and projects, the three coarse
-#                                                               layer_rn convs, resize_layers 1 and 3.  8 x 1022^2: 9.1e-4 at 36.6 images/s
+#                                                               layer_rn convs, resize_layers 1 and 3.  8 x 1022^2: 9.1e-4 at 37.4 images/s
 #                                                               (everything split: 8.7e-4 at 28.4; nothing: 1.3e-3 at 41.3).  Splitting the
 #                                                               ResidualConvUnit convs makes ViT-G parity WORSE (1.13e-3 -> 1.31e-3).
 _RAW_VITG_SPLIT = ("oc2", "out", "rn1", "rn2", "rn3", "proj", "rs1", "rs3")

@@ -18,6 +18,26 @@ ADA_DEV void store_op4_split(op_t* row, int c, float4 r, int split_seg) {
     }
 }
 
+#ifdef ADA_NT_BIL    // A/B: non-temporal stores of the resize kernels' outputs
+ADA_DEV void store_op4_bil(op_t* row, int c, float4 r, int split_seg) {
+    opx4 o;
+    o[0] = to_op(r.x); o[1] = to_op(r.y); o[2] = to_op(r.z); o[3] = to_op(r.w);
+    __builtin_nontemporal_store(o, ((opx4*)row) + c);
+    if (split_seg > 0) {
+        opx4 l;
+        l[0] = to_op(r.x - (float)o[0]); l[1] = to_op(r.y - (float)o[1]); l[2] = to_op(r.z - (float)o[2]); l[3] = to_op(r.w - (float)o[3]);
+        __builtin_nontemporal_store(l, ((opx4*)(row + split_seg)) + c);
+    }
+}
+ADA_DEV void store_f32_bil(float* ptr, float4 r) {
+    const f32x4 t = {r.x, r.y, r.z, r.w};
+    __builtin_nontemporal_store(t, (f32x4*)ptr);
+}
+#else
+ADA_DEV void store_op4_bil(op_t* row, int c, float4 r, int split_seg) { store_op4_split(row, c, r, split_seg); }
+ADA_DEV void store_f32_bil(float* ptr, float4 r) { *(float4*)ptr = r; }
+#endif
+
 constexpr int LN_MAX_CHUNKS = 6;  // float4 chunks per lane: dim <= 6 * 64 * 4 = 1536
 
 ADA_DEV float wave_sum(float v) {
@@ -216,7 +236,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(BilinearArgs p) {
         const float4 a = ((const float4*)(p.add + pix * p.ld_add))[c];
         r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
     }
-    if (p.out_f32) ((float4*)(p.out_f32 + pix * p.ld_f32))[c] = r;
+    if (p.out_f32) store_f32_bil(p.out_f32 + pix * p.ld_f32 + 4 * c, r);
     if (p.out_op) {
         long orow = pix;
         if (p.map_op == ADA_MAP_PAD) orow = ((long)b * (p.ho + 2) + (y + 1)) * (p.wo + 2) + (x + 1);
@@ -224,7 +244,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(BilinearArgs p) {
             r.x = __builtin_fmaxf(r.x, 0.f); r.y = __builtin_fmaxf(r.y, 0.f);
             r.z = __builtin_fmaxf(r.z, 0.f); r.w = __builtin_fmaxf(r.w, 0.f);
         }
-        store_op4_split(p.out_op + orow * p.ld_op, c, r, p.split_seg);
+        store_op4_bil(p.out_op + orow * p.ld_op, c, r, p.split_seg);
     }
 }
 
@@ -288,7 +308,7 @@ __global__ __launch_bounds__(256) void bilinear_tiled_kernel(BilinearArgs p, int
             const float4 a = ((const float4*)(p.add + pix * p.ld_add))[c];
             r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
         }
-        if (p.out_f32) ((float4*)(p.out_f32 + pix * p.ld_f32))[c] = r;
+        if (p.out_f32) store_f32_bil(p.out_f32 + pix * p.ld_f32 + 4 * c, r);
         if (p.out_op) {
             long orow = pix;
             if (p.map_op == ADA_MAP_PAD) orow = ((long)b * (p.ho + 2) + (y + 1)) * (p.wo + 2) + (x + 1);
@@ -296,7 +316,7 @@ __global__ __launch_bounds__(256) void bilinear_tiled_kernel(BilinearArgs p, int
                 r.x = __builtin_fmaxf(r.x, 0.f); r.y = __builtin_fmaxf(r.y, 0.f);
                 r.z = __builtin_fmaxf(r.z, 0.f); r.w = __builtin_fmaxf(r.w, 0.f);
             }
-            store_op4_split(p.out_op + orow * p.ld_op, c, r, p.split_seg);
+            store_op4_bil(p.out_op + orow * p.ld_op, c, r, p.split_seg);
         }
     }
 }

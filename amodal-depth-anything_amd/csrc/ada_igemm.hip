@@ -34,6 +34,28 @@ namespace {
 
 enum { EPI_STD = 0, EPI_GELU = 1, EPI_SHUFFLE = 2, EPI_SWIGLU = 3, EPI_TAIL = 4 };
 
+// Non-temporal hints on the streaming traffic of the epilogues (round 3 A/B) -- bit 0: the fp32 residual loads, bit 1: the fp32 stores (both
+// neutral end to end: off), bit 2: the 16-byte operand-typed stores (+1.0 % end to end: ON).
+#ifndef ADA_EPI_NT
+#define ADA_EPI_NT 4
+#endif
+ADA_DEV float4 ld_res4(const float* ptr) {
+#if ADA_EPI_NT & 1
+    const f32x4 v = __builtin_nontemporal_load((const f32x4*)ptr);
+    return make_float4(v[0], v[1], v[2], v[3]);
+#else
+    return *(const float4*)ptr;
+#endif
+}
+ADA_DEV void st_f32x4(float* ptr, float4 v) {
+#if ADA_EPI_NT & 2
+    const f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (f32x4*)ptr);
+#else
+    *(float4*)ptr = v;
+#endif
+}
+
 struct IgemmDev {
     int M, N, K, a_mode;
     const op_t* A;
@@ -163,7 +185,16 @@ ADA_DEV void store_op8(const IgemmDev& p, op_t* dst, float4 v0, float4 v1) {
     opx8 o;
     o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
     o[4] = hi4[0]; o[5] = hi4[1]; o[6] = hi4[2]; o[7] = hi4[3];
+    // The 16-byte operand-typed stores are non-temporal: the output of a linear layer / conv is written once here and read by the NEXT
+    // kernel; streamed past the caches it does not push this GEMM's weight slabs and A panels out of L2 (fc1 + GELU 427 -> 390 us per
+    // launch, +1.0 % end to end: profiles/r03_o_nontemporal_stores_ab.txt).  Compile-time on purpose: behind a runtime branch the
+    // optimiser merges the two stores and drops the hint (checked in the .s).  The same hint on the 8-byte stores, on the attention output,
+    // on LayerNorm / bilinear outputs and on the fp32 residual traffic measured neutral or negative.
+#if ADA_EPI_NT & 4
+    __builtin_nontemporal_store(o, (opx8*)dst);
+#else
     *(opx8*)dst = o;
+#endif
     if (p.split_seg > 0) {
         float4 r0, r1;
         r0.x = v0.x - (float)lo[0]; r0.y = v0.y - (float)lo[1]; r0.z = v0.z - (float)lo[2]; r0.w = v0.w - (float)lo[3];
@@ -644,7 +675,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             if (AHEAD && has_res) {
                 const float* r0 = rptr(0);
 #pragma unroll
-                for (int k = 0; k < NKI; ++k) rcur[k] = *(const float4*)(r0 + (long)(k * RPI) * ldr);
+                for (int k = 0; k < NKI; ++k) rcur[k] = ld_res4(r0 + (long)(k * RPI) * ldr);
             }
 #pragma unroll
             for (int q = 0; q < NPASS; ++q) {
@@ -658,12 +689,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                         if (q + 1 < NPASS) {
                             const float* r1 = rptr(q + 1);
 #pragma unroll
-                            for (int k = 0; k < NKI; ++k) rnext[k] = *(const float4*)(r1 + (long)(k * RPI) * ldr);
+                            for (int k = 0; k < NKI; ++k) rnext[k] = ld_res4(r1 + (long)(k * RPI) * ldr);
                         }
                     } else {
                         const float* r0 = rptr(q);
 #pragma unroll
-                        for (int k = 0; k < NKI; ++k) rcur[k] = *(const float4*)(r0 + (long)(k * RPI) * ldr);
+                        for (int k = 0; k < NKI; ++k) rcur[k] = ld_res4(r0 + (long)(k * RPI) * ldr);
                     }
                 }
                 dump(i, g);
@@ -687,7 +718,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                             w.x = __builtin_fmaxf(w.x, 0.f); w.y = __builtin_fmaxf(w.y, 0.f);
                             w.z = __builtin_fmaxf(w.z, 0.f); w.w = __builtin_fmaxf(w.w, 0.f);
                         }
-                        *(float4*)(p.out_f32 + (mrow + k * RPI) * ldf + n) = w;
+                        st_f32x4(p.out_f32 + (mrow + k * RPI) * ldf + n, w);
                     }
                     if (p.out_op) {
                         if (relu_o) {

@@ -18,7 +18,8 @@ ADA_DEV void store_op4_split(op_t* row, int c, float4 r, int split_seg) {
     }
 }
 
-#ifdef ADA_NT_BIL    // A/B: non-temporal stores of the resize kernels' outputs
+// The resize kernels' outputs are written once and read by a later launch: non-temporal stores keep them
+// from displacing the input rows the neighbouring workgroups still read (profiles/r03_o, +0.3 % end to end).
 ADA_DEV void store_op4_bil(op_t* row, int c, float4 r, int split_seg) {
     opx4 o;
     o[0] = to_op(r.x); o[1] = to_op(r.y); o[2] = to_op(r.z); o[3] = to_op(r.w);
@@ -33,10 +34,6 @@ ADA_DEV void store_f32_bil(float* ptr, float4 r) {
     const f32x4 t = {r.x, r.y, r.z, r.w};
     __builtin_nontemporal_store(t, (f32x4*)ptr);
 }
-#else
-ADA_DEV void store_op4_bil(op_t* row, int c, float4 r, int split_seg) { store_op4_split(row, c, r, split_seg); }
-ADA_DEV void store_f32_bil(float* ptr, float4 r) { *(float4*)ptr = r; }
-#endif
 
 constexpr int LN_MAX_CHUNKS = 6;  // float4 chunks per lane: dim <= 6 * 64 * 4 = 1536
 

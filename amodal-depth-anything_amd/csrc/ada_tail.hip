@@ -4,30 +4,38 @@
 // scratch.output_conv2 = Conv2d(C, 32, 3, padding 1) -> ReLU -> Conv2d(32, 1, 1) -> Sigmoid / ReLU / Identity -- in ONE kernel.
 //
 // The two-kernel path materialises the up-sampled map ("fin": [B, H+2, W+2, C] operand-typed, 2.2 GB at ViT-L bs=32), writes it
-// once and re-reads it nine times through L2 from a 32-column GEMM whose A tile is all traffic and no reuse (0.80 ms + 1.31 ms).
-// Here a workgroup owns an 8 x 32 block of output pixels:
-//   1. the source patch of `in` (fp32 NHWC rows) under the block's 10 x 34 halo is copied once into LDS by LDS-DMA (64 channels per pass);
-//   2. the halo tile is interpolated from LDS into LDS, operand-typed, zero outside the image (= the convolution's padding), each pixel a
-//      128-byte row whose 16-byte chunks are XOR-swizzled so that the fragment reads below are bank-conflict free;
-//   3. the 3 x 3 convolution runs as 9 taps x 2 k-steps of v_mfma_f32_16x16x32 straight from the halo tile (a tap is a constant row /
-//      column shift of the fragment address) against the weights of this channel pass, staged once per pass in LDS;
-//   4. bias, ReLU, the 32 -> 1 projection (16-lane xor-shuffle reduction), activation, one fp32 store per pixel.
-// Nothing but `in`, the 73 KB of weights and the output touches HBM / L2.
+// once and re-reads it nine times through L2 from a 32-column GEMM whose A tile is all traffic and no reuse (0.8 ms + 1.3 ms).
+// Here nothing but `in`, the weights and the output touches HBM / L2.
+//
+// Persistent launch, one 8-wave workgroup per CU walking tiles of 8 x 30 output pixels; a tile is processed as `passes` units of 64
+// input channels.  The two waves of a SIMD have different jobs, so that the SIMD's VALU and its matrix pipe work at the same time:
+//   * waves 4-7 (producers) build the unit's 10 x 32 halo tile in LDS: thread (halo column, 8 channels) fetches the two source
+//     pixels of its column for the 8 source rows under the halo straight into registers (fp32, 32 B per pixel and lane, issued a
+//     whole unit ahead so they land under the consumers' MFMAs), interpolates horizontally once per source row, then walks down the
+//     halo rows interpolating vertically, and stores operand-typed 16-byte chunks -- zero outside the image (= the convolution's
+//     padding) -- XOR-swizzled so that the consumers' fragment reads are bank-conflict free;
+//   * waves 0-3 (consumers) run the 3 x 3 convolution of the previous unit from the other halo buffer: 9 taps x 2 k-steps of
+//     v_mfma_f32_16x16x32 (a tap is a constant row / column shift of the fragment address) against the weights, which stay resident
+//     in LDS for the life of the workgroup; after the last unit of a tile: bias, ReLU, 32 -> 1 (DPP row reduction), activation, store.
+// One barrier per unit hands the buffers over.
 #include <mutex>
-#include <stdlib.h>
 #include "ada_common.h"
+#ifndef TAIL_ABL
+#define TAIL_ABL 0   // timing experiments: 1 no convolution, 2 no interpolation arithmetic, 4 no fetches
+#endif
 
 namespace {
 
-constexpr int T_TH = 8, T_TW = 32;                 // output pixels per workgroup
-constexpr int T_HH = T_TH + 2, T_HW = T_TW + 2;    // halo
-constexpr int T_NPIX = T_HH * T_HW;                // 340 halo pixels
-constexpr int T_CH = 64;                           // channels per pass
+constexpr int T_TH = 8, T_TW = 30;                 // output pixels per tile (the fragments cover 32 columns: two are discarded)
+constexpr int T_HH = T_TH + 2, T_HW = 32;          // halo tile
+constexpr int T_CH = 64;                           // channels per unit
 constexpr int T_PIXB = T_CH * 2;                   // bytes per halo pixel (128)
 constexpr int T_N = 32;                            // output channels of the 3x3 convolution
 constexpr int T_WROW = 9 * T_PIXB;                 // bytes per weight row in LDS (9 taps x 64 channels)
-constexpr int T_HALO_BYTES = T_NPIX * T_PIXB;      // 43520
-constexpr int T_W_BYTES = T_N * T_WROW;            // 36864
+constexpr int T_W_BYTES = T_N * T_WROW;            // 36864 per pass
+constexpr int T_HALO_BYTES = T_HH * T_HW * T_PIXB + 2 * T_PIXB;   // 41216: the fragments of the two discarded columns read 2 pixels on
+constexpr int T_MAX_PASSES = 2;                    // weights of all passes are LDS-resident: 2 * 41216 + 2 * 36864 = 156160 B
+constexpr int T_ROWS = 8;                          // source rows fetched per halo tile: the tile's 10 rows must span <= 7 row intervals
 
 struct TailArgs {
     const float* in;
@@ -41,39 +49,159 @@ struct TailArgs {
     float tail_b;
     int tail_act;
     float* out;
-    int pw_max;                          // patch row stride bound used for the LDS carve (host-computed)
-    int ablate;                          // timing experiments (ADA_TAIL_ABLATE): 1 no staging, 2 no interpolation, 4 no convolution
+    int ntx, nty, ntiles;
 };
 
-__global__ __launch_bounds__(256, 1) void dpt_tail_kernel(TailArgs p) {
+// sum over the 16 lanes of a DPP row, result in every lane (row_ror 8, 4, 2, 1)
+ADA_DEV float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
+struct TileAt {
+    int b, ty0, tx0;
+};
+
+__global__ __launch_bounds__(512, 1) void dpt_tail_kernel(TailArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const halo = smem;
-    char* const wbuf = smem + T_HALO_BYTES;
-    char* const src = smem + T_HALO_BYTES + T_W_BYTES;
+    char* const wbuf = smem + 2 * T_HALO_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= 4;
     const int l15 = lane & 15, q4 = lane >> 4;
-    const int tx0 = blockIdx.x * T_TW, ty0 = blockIdx.y * T_TH, b = blockIdx.z;
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int nunits = ((p.ntiles - bid + G - 1) / G) * p.passes;
 
-    // source patch under the halo (clamped to the image): rows py0 .. py1, columns px0 .. px1
-    const int oy0 = ty0 > 0 ? ty0 - 1 : 0, oy1 = min(ty0 + T_TH, p.ho - 1);
-    const int ox0 = tx0 > 0 ? tx0 - 1 : 0, ox1 = min(tx0 + T_TW, p.wo - 1);
-    const int py0 = (int)(p.sy * (float)oy0), px0 = (int)(p.sx * (float)ox0);
-    const int py1 = min((int)(p.sy * (float)oy1) + 1, p.hi - 1), px1 = min((int)(p.sx * (float)ox1) + 1, p.wi - 1);
-    const int ph = py1 - py0 + 1, pw = px1 - px0 + 1;
-    const int npatch = ph * pw;
-    const long img = (long)b * p.hi;
+    auto tile_of = [&](int u) -> TileAt {
+        const int ti = bid + (u / p.passes) * G;
+        const int per_img = p.ntx * p.nty;
+        const int b = ti / per_img, rem = ti - b * per_img;
+        const int tyi = rem / p.ntx;
+        return TileAt{b, tyi * T_TH, (rem - tyi * p.ntx) * T_TW};
+    };
 
-    f32x4 acc[4][2];
+    // ---- weights of every pass -> LDS, once: [pass][n][tap][64 channels], 16-byte chunks XOR-swizzled with (n >> 1) & 7 ----
+    // k order inside a 64-channel block: chunk c = channels 4c..4c+3 and 32+4c..32+4c+3 (the same permutation on both MFMA operands).
+    // A producer lane then fetches two 16-byte pieces that are contiguous with its neighbours': a fetch instruction touches 8 full
+    // 128-byte lines instead of 16 half-used ones (the L1 moves whole lines: this halved the producers' fetch time).
+    for (int q = tid; q < p.passes * (T_N * 72); q += 512) {   // chunks of 16 B: (pass, n, tap, chunk)
+        const int pass = q / (T_N * 72), r0 = q - pass * (T_N * 72);
+        const int n = r0 / 72, rem = r0 - n * 72, t = rem >> 3, c = rem & 7;
+        const op_t* g = p.w + (long)n * (9 * p.cp) + t * p.cp + pass * T_CH + 4 * c;
+        const u32x2 lo = *(const u32x2*)g, hi = *(const u32x2*)(g + 32);
+        *(u32x4*)(wbuf + pass * T_W_BYTES + n * T_WROW + t * T_PIXB + ((c ^ ((n >> 1) & 7)) * 16)) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    }
+
+    // ---- producer state: thread (halo column hx, chunk pc) ----
+    const int pt = tid & 255;
+    const int hx = pt >> 3, pc = pt & 7;
+    const unsigned pdst = (unsigned)(hx * T_PIXB + ((pc ^ ((hx >> 1) & 7)) * 16));
+    f32x4 v[T_ROWS][4];
+#if TAIL_ABL & 4
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int r = 0; r < T_ROWS; ++r)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i) v[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+    // v: source row r: pixel x0 (channels 4 pc .. 4 pc + 3 and 32 + 4 pc .. 32 + 4 pc + 3 of the unit), pixel x1 (same)
+    struct Src {               // where a unit's source rows are: per-lane element offsets of the two pixels, first row, image
+        long o0, o1;
+        int py0, b;
+    };
+    auto src_of = [&](int u) -> Src {
+        const TileAt t = tile_of(u);
+        const int pass = u % p.passes;
+        int x = t.tx0 - 1 + hx;
+        x = x < 0 ? 0 : (x > p.wo - 1 ? p.wo - 1 : x);
+        const int x0 = (int)(p.sx * (float)x);
+        const int x1 = x0 + (x0 < p.wi - 1 ? 1 : 0);
+        const int yv = t.ty0 > 0 ? t.ty0 - 1 : 0;
+        return Src{(long)x0 * p.ld_in + pass * T_CH + pc * 4, (long)x1 * p.ld_in + pass * T_CH + pc * 4, (int)(p.sy * (float)yv), t.b};
+    };
+    // The fetches are inline assembly with hand-counted s_waitcnt: written as C++ loads the compiler gives the rows of the next unit fresh
+    // registers and copies them into place at the loop's back edge -- behind an "s_waitcnt vmcnt(0)" that puts the whole fetch latency
+    // back on the critical path.  Every wait names the row's registers as in/out operands, so no use of a row can be scheduled above it.
+    auto fetch_row = [&](const Src& q, int r) {
+        const int gy = q.py0 + r < p.hi - 1 ? q.py0 + r : p.hi - 1;
+        const float* row = p.in + ((long)q.b * p.hi + gy) * p.wi * p.ld_in;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[r][0]) : "v"(row + q.o0));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[r][1]) : "v"(row + q.o0 + 32));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[r][2]) : "v"(row + q.o1));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[r][3]) : "v"(row + q.o1 + 32));
+    };
+#define TAIL_WAIT_ROW(r, n) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[r][0]), "+v"(v[r][1]), "+v"(v[r][2]), "+v"(v[r][3]) : "n"(n))
+    // Builds unit u's halo tile from the rows in v and, row by row as they are used up, re-issues the fetches of unit u + 1 into the same
+    // registers: every row then has a whole unit of interpolation arithmetic plus the barrier wait to land in.  (Fetching all of unit u + 1
+    // after unit u is done leaves only the barrier wait: ~2 us of exposed latency per unit, profiles/r03_p_fused_tail.txt.)
+    auto interpolate = [&](int u, bool more) {
+        const TileAt t = tile_of(u);
+        const Src nx = src_of(more ? u + 1 : u);
+        char* const dst = smem + (u & 1) * T_HALO_BYTES + pdst;
+        const int x = t.tx0 - 1 + hx;
+        const bool xin = x >= 0 && x < p.wo;
+        const int xc = x < 0 ? 0 : (x > p.wo - 1 ? p.wo - 1 : x);
+        const float fx = p.sx * (float)xc;
+        const float lx1 = fx - (float)(int)fx, lx0 = 1.0f - lx1;
+        const int yv = t.ty0 > 0 ? t.ty0 - 1 : 0;
+        const int py0 = (int)(p.sy * (float)yv);
+        // horizontal interpolation of source row r (computed when the walk below reaches it: the fetched pixels die as they are used)
+        // Fetches retire in issue order.  When row r of this unit is needed, the rows after it (4 fetches each) and the rows 0 .. r - 1 of the
+        // next unit, issued since, may still be in flight: always 28 fetches -- the last unit of a workgroup fetches itself again rather
+        // than take a second code path (two paths make the row registers phi nodes, which the compiler copies while they are in flight).
+        auto hrow = [&](int r, float* h) {
+            h[0] = lx0 * v[r][0][0] + lx1 * v[r][2][0]; h[1] = lx0 * v[r][0][1] + lx1 * v[r][2][1];
+            h[2] = lx0 * v[r][0][2] + lx1 * v[r][2][2]; h[3] = lx0 * v[r][0][3] + lx1 * v[r][2][3];
+            h[4] = lx0 * v[r][1][0] + lx1 * v[r][3][0]; h[5] = lx0 * v[r][1][1] + lx1 * v[r][3][1];
+            h[6] = lx0 * v[r][1][2] + lx1 * v[r][3][2]; h[7] = lx0 * v[r][1][3] + lx1 * v[r][3][3];
+        };
+        opx8 zero;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zero[e] = (op_t)0.0f;
+        int hy = 0;
+        if (t.ty0 == 0) {   // the row above the image
+            *(opx8*)dst = zero;
+            hy = 1;
+        }
+        float ha[8], hb[8];
+#if !(TAIL_ABL & 4)
+        TAIL_WAIT_ROW(0, 28);
+#endif
+        hrow(0, hb);
+        if (!(TAIL_ABL & 4)) fetch_row(nx, 0);
+#pragma unroll
+        for (int r = 0; r < T_ROWS - 1; ++r) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ha[e] = hb[e];
+#if !(TAIL_ABL & 4)
+            TAIL_WAIT_ROW(r + 1, 28);
+#endif
+            hrow(r + 1, hb);
+            if (!(TAIL_ABL & 4)) fetch_row(nx, r + 1);
+            while (hy < T_HH) {   // halo rows whose upper source row is py0 + r (wave-uniform: 0, 1 or 2 of them when up-sampling)
+                const int y = t.ty0 - 1 + hy;
+                if (y >= p.ho) break;
+                const float fy = p.sy * (float)y;
+                const int y0 = (int)fy;
+                if (y0 != py0 + r) break;
+                const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1;
+                opx8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = to_op(ly0 * ha[e] + ly1 * hb[e]);
+                *(opx8*)(dst + hy * (T_HW * T_PIXB)) = xin ? o : zero;
+                ++hy;
+            }
+        }
+        for (; hy < T_HH; ++hy) *(opx8*)(dst + hy * (T_HW * T_PIXB)) = zero;   // rows below the image
+    };
 
-    // fragment addresses: A rows are halo pixels (2 * wave + (f >> 1) + dy, 16 * (f & 1) + dx + l15); the 16-byte chunk of a pixel row is
-    // XOR-ed with (column >> 1) & 7, so 16 consecutive pixels of one halo row hit 16 distinct bank slots for any starting column
+    // ---- consumer state: wave w owns output rows 2w, 2w+1 of the tile; fragment f = (row f >> 1, column half f & 1) ----
+    // A rows are halo pixels (2 * wave + (f >> 1) + dy, 16 * (f & 1) + dx + l15); the 16-byte chunk of a pixel row is XOR-ed with
+    // (column >> 1) & 7, so 16 consecutive pixels of one halo row hit 16 distinct bank slots for any starting column
     unsigned abase[2][3][2], bbase[2][2];
 #pragma unroll
     for (int fx = 0; fx < 2; ++fx)
@@ -81,121 +209,95 @@ __global__ __launch_bounds__(256, 1) void dpt_tail_kernel(TailArgs p) {
         for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const int hx = 16 * fx + dx + l15;
-                abase[fx][dx][s] = (unsigned)((2 * wave * T_HW + hx) * T_PIXB + (((4 * s + q4) ^ ((hx >> 1) & 7)) * 16));
+                const int ax = 16 * fx + dx + l15;
+                abase[fx][dx][s] = (unsigned)((2 * (wave & 3) * T_HW + ax) * T_PIXB + (((4 * s + q4) ^ ((ax >> 1) & 7)) * 16));
             }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int n = 16 * j + l15;
-            bbase[j][s] = (unsigned)(T_HALO_BYTES + n * T_WROW + (((4 * s + q4) ^ ((n >> 1) & 7)) * 16));
+            bbase[j][s] = (unsigned)(2 * T_HALO_BYTES + n * T_WROW + (((4 * s + q4) ^ ((n >> 1) & 7)) * 16));
         }
+    f32x4 acc[4][2];
+    float b0 = 0.f, b1 = 0.f, w0 = 0.f, w1 = 0.f;   // fetched by the consumers only: a pending load in a producer wave would be waited for with vmcnt(0) inside its loop
 
-    for (int pass = 0; pass < p.passes; ++pass) {
-        // ---- 1. source patch -> LDS (16 pixels of 64 fp32 channels per round, lane-linear: 256 B per pixel) and weights -> LDS ----
-        if (!(p.ablate & 1))
-        for (int base = 0; base < npatch; base += 16) {
-            int pp = base + (tid >> 4);
-            if (pp >= npatch) pp = npatch - 1;
-            const int r = pp / pw, c = pp - r * pw;
-            const float* g = p.in + ((img + py0 + r) * p.wi + (px0 + c)) * p.ld_in + pass * T_CH + 4 * (tid & 15);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(src + base * 256 + wave * 1024), 16, 0, 0);
-        }
-        if (!(p.ablate & 1))
+    auto convolve = [&](int u) {
+        const int pass = u % p.passes;
+        if (pass == 0) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int q = tid + 256 * i;            // 2304 chunks of 16 B: (n, tap, chunk)
-            const int n = q / 72, rem = q - n * 72, t = rem >> 3, c = rem & 7;
-            const u32x4 v = *(const u32x4*)(p.w + (long)n * (9 * p.cp) + t * p.cp + pass * T_CH + 8 * c);
-            *(u32x4*)(wbuf + n * T_WROW + t * T_PIXB + ((c ^ ((n >> 1) & 7)) * 16)) = v;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-
-        // ---- 2. halo tile = bilinear(source patch), operand-typed, zero outside the image ----
-        if (!(p.ablate & 2))
-        for (int item = tid; item < T_NPIX * 8; item += 256) {
-            const int hp = item >> 3, c = item & 7;
-            const int hy = hp / T_HW, hx = hp - hy * T_HW;
-            const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
-            opx8 o;
+            for (int f = 0; f < 4; ++f)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (op_t)0.0f;
-            if (y >= 0 && y < p.ho && x >= 0 && x < p.wo) {
-                const float fy = p.sy * (float)y, fx = p.sx * (float)x;
-                const int y0 = (int)fy, x0 = (int)fx;
-                const int y1 = y0 + (y0 < p.hi - 1 ? 1 : 0), x1 = x0 + (x0 < p.wi - 1 ? 1 : 0);
-                const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
-                const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
-                const char* t0 = src + ((y0 - py0) * pw - px0) * 256 + c * 32;
-                const char* t1 = src + ((y1 - py0) * pw - px0) * 256 + c * 32;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float4 v00 = *(const float4*)(t0 + x0 * 256 + h * 16);
-                    const float4 v01 = *(const float4*)(t0 + x1 * 256 + h * 16);
-                    const float4 v10 = *(const float4*)(t1 + x0 * 256 + h * 16);
-                    const float4 v11 = *(const float4*)(t1 + x1 * 256 + h * 16);
-                    o[4 * h + 0] = to_op(ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x));
-                    o[4 * h + 1] = to_op(ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y));
-                    o[4 * h + 2] = to_op(ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z));
-                    o[4 * h + 3] = to_op(ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w));
-                }
-            }
-            *(opx8*)(halo + hp * T_PIXB + ((c ^ ((hx >> 1) & 7)) * 16)) = o;
+                for (int j = 0; j < 2; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        __syncthreads();
-
-        // ---- 3. 3x3 convolution from the halo tile: 9 taps x 2 k-steps of 32 channels ----
-        if (!(p.ablate & 4))
+        const char* const ha = smem + (u & 1) * T_HALO_BYTES;
+        const char* const wb = smem + pass * T_W_BYTES;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                for (int k = 0; k < 2; ++k) {
                     opx8 af[4], bf[2];
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) af[f] = *(const opx8*)(smem + abase[f & 1][dx][s] + ((f >> 1) + dy) * (T_HW * T_PIXB));
+                    for (int f = 0; f < 4; ++f) af[f] = *(const opx8*)(ha + abase[f & 1][dx][k] + ((f >> 1) + dy) * (T_HW * T_PIXB));
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bf[j] = *(const opx8*)(smem + bbase[j][s] + (dy * 3 + dx) * T_PIXB);
+                    for (int j = 0; j < 2; ++j) bf[j] = *(const opx8*)(wb + bbase[j][k] + (dy * 3 + dx) * T_PIXB);
 #pragma unroll
                     for (int f = 0; f < 4; ++f)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) acc[f][j] = mfma16(af[f], bf[j], acc[f][j]);
                 }
-        __syncthreads();   // every wave is done with the halo tile, the weights and (long since) the source patch of this pass
-    }
-
-    // ---- 4. bias, ReLU, 32 -> 1, activation.  D[4 * q4 + r][l15]: row = pixel inside the 16-pixel fragment, column = output channel ----
-    const float b0 = p.bias[l15], b1 = p.bias[16 + l15], w0 = p.tail_w[l15], w1 = p.tail_w[16 + l15];
+        if (pass != p.passes - 1) return;
+        // bias, ReLU, 32 -> 1, activation.  D[4 * q4 + r][l15]: row = pixel inside the 16-pixel fragment, column = output channel
+        const TileAt t = tile_of(u);
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        float v[4];
+        for (int f = 0; f < 4; ++f) {
+            float d[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            v[r] = __builtin_fmaxf(acc[f][0][r] + b0, 0.0f) * w0 + __builtin_fmaxf(acc[f][1][r] + b1, 0.0f) * w1;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) v[r] += __shfl_xor(v[r], o);
-        }
-        if (l15 == 0) {
-            const int y = ty0 + 2 * wave + (f >> 1);
-            if (y < p.ho) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int x = tx0 + 16 * (f & 1) + 4 * q4 + r;
-                    if (x < p.wo) {
-                        float d = v[r] + p.tail_b;
-                        if (p.tail_act == ADA_ACT_SIGMOID) d = 1.0f / (1.0f + __expf(-d));
-                        else if (p.tail_act == ADA_ACT_RELU) d = __builtin_fmaxf(d, 0.0f);
-                        p.out[((long)b * p.ho + y) * p.wo + x] = d;
-                    }
-                }
+            for (int r = 0; r < 4; ++r)
+                d[r] = row16_sum(__builtin_fmaxf(acc[f][0][r] + b0, 0.0f) * w0 + __builtin_fmaxf(acc[f][1][r] + b1, 0.0f) * w1) + p.tail_b;
+            const int y = t.ty0 + 2 * wave + (f >> 1);
+            if (l15 < 4 && y < p.ho) {   // lane l15 = r stores pixel r of its quarter: four consecutive floats per 16-lane row
+                const int cx = 16 * (f & 1) + 4 * q4 + l15, x = t.tx0 + cx;
+                float o = l15 == 0 ? d[0] : (l15 == 1 ? d[1] : (l15 == 2 ? d[2] : d[3]));
+                if (p.tail_act == ADA_ACT_SIGMOID) o = 1.0f / (1.0f + __expf(-o));
+                else if (p.tail_act == ADA_ACT_RELU) o = __builtin_fmaxf(o, 0.0f);
+                if (cx < T_TW && x < p.wo) p.out[((long)t.b * p.ho + y) * p.wo + x] = o;
             }
+        }
+    };
+
+    // ---- the pipeline: during step u the producers build unit u while the consumers convolve unit u - 1 ----
+    // Two loops with the same number of barriers (the branch is wave-uniform; s_barrier counts waves, whichever loop they are in): the
+    // producers' 128 registers of pixels in flight are not live in the consumers' code and the other way round.
+    if (producer) {
+        if (nunits > 0 && !(TAIL_ABL & 4)) {
+            const Src q = src_of(0);
+#pragma unroll
+            for (int r = 0; r < T_ROWS; ++r) fetch_row(q, r);
+        }
+        for (int u = 0; u <= nunits; ++u) {
+            if (u < nunits && !(TAIL_ABL & 2)) interpolate(u, u + 1 < nunits);
+            __syncthreads();
+        }
+        asm volatile("s_waitcnt vmcnt(0)");   // the last unit's spare fetches
+    } else {
+        const float* bias = p.bias;
+        const float* tail_w = p.tail_w;
+        asm volatile("" : "+s"(bias), "+s"(tail_w));   // keeps the four loads in this branch ...
+        b0 = bias[l15]; b1 = bias[16 + l15]; w0 = tail_w[l15]; w1 = tail_w[16 + l15];
+        // ... and waited for here: the structurised CFG has a (never taken) path from this branch into the producers' one, and a load the compiler
+        // believes pending there costs an "s_waitcnt vmcnt(0)" in the middle of the producers' loop, i.e. their whole fetch latency, every unit
+        asm volatile("" ::"v"(b0), "v"(b1), "v"(w0), "v"(w1));
+        for (int u = 0; u <= nunits; ++u) {
+            if (u >= 1 && !(TAIL_ABL & 1)) convolve(u - 1);
+            __syncthreads();
         }
     }
 }
+
+int g_tail_cus = 0;
 
 }  // namespace
 
@@ -203,33 +305,33 @@ extern "C" int ada_dpt_tail_fwd(const float* in, int64_t ld_in, int32_t batch, i
                                 const void* w, const float* bias, const float* tail_w, float tail_b, int32_t tail_act, float* out,
                                 void* stream) {
     ADA_REQUIRE(in && w && bias && tail_w && out, ADA_EINVAL, "ada_dpt_tail_fwd: null pointer");
-    ADA_REQUIRE(batch > 0 && batch <= 65535 && hi > 0 && wi > 0 && ho > 0 && wo > 0, ADA_EINVAL, "ada_dpt_tail_fwd: bad shape");
-    ADA_REQUIRE(cp > 0 && cp % T_CH == 0 && ld_in >= cp && ld_in % 4 == 0, ADA_EUNSUPPORTED,
-                "ada_dpt_tail_fwd: the padded channel count (%d) must be a multiple of 64 and fit the input row (ld_in=%ld)", cp, (long)ld_in);
+    ADA_REQUIRE(batch > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0, ADA_EINVAL, "ada_dpt_tail_fwd: bad shape");
+    ADA_REQUIRE(cp > 0 && cp % T_CH == 0 && cp / T_CH <= T_MAX_PASSES && ld_in >= cp && ld_in % 4 == 0, ADA_EUNSUPPORTED,
+                "ada_dpt_tail_fwd: the padded channel count (%d) must be 64 or 128 and fit the input row (ld_in=%ld)", cp, (long)ld_in);
     ADA_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)w % 16) == 0, ADA_EINVAL, "ada_dpt_tail_fwd: in / w must be 16-byte aligned");
     TailArgs p;
     p.in = in; p.ld_in = ld_in; p.batch = batch; p.hi = hi; p.wi = wi; p.ho = ho; p.wo = wo; p.passes = cp / T_CH;
     p.sy = ho > 1 ? (float)(hi - 1) / (float)(ho - 1) : 0.0f;
     p.sx = wo > 1 ? (float)(wi - 1) / (float)(wo - 1) : 0.0f;
+    // the producers hold T_ROWS source rows per halo tile in registers: the tile's 10 rows may span at most T_ROWS - 1 row intervals
+    ADA_REQUIRE((int)(p.sy * (float)(T_HH - 1)) + 2 <= T_ROWS - 1, ADA_EUNSUPPORTED,
+                "ada_dpt_tail_fwd: vertical scale %d -> %d is not supported (needs ho >= 1.5 hi; the model's ratio is 14 / 8)", hi, ho);
     p.w = (const op_t*)w; p.cp = cp; p.bias = bias; p.tail_w = tail_w; p.tail_b = tail_b; p.tail_act = tail_act; p.out = out;
-    // LDS carve: the largest source patch a block can need
-    const int ph_max = (int)(p.sy * (float)(T_TH + 1)) + 3, pw_max = (int)(p.sx * (float)(T_TW + 1)) + 3;
-    const int npatch_max = ((ph_max * pw_max + 15) / 16) * 16;
-    const size_t smem = (size_t)T_HALO_BYTES + T_W_BYTES + (size_t)npatch_max * 256;
-    ADA_REQUIRE(smem <= 160 * 1024, ADA_EUNSUPPORTED, "ada_dpt_tail_fwd: source patch of %d x %d pixels does not fit in LDS (down-sampling is not supported)", ph_max, pw_max);
-    p.pw_max = pw_max;
-#ifdef ADA_TAIL_ABLATION   // timing experiments only (csrc/build.py --tag abl -D ADA_TAIL_ABLATION): never in the shipped library
-    {
-        const char* e = getenv("ADA_TAIL_ABLATE");
-        p.ablate = e ? atoi(e) : 0;
-    }
-#else
-    p.ablate = 0;
-#endif
+    p.ntx = (wo + T_TW - 1) / T_TW;
+    p.nty = (ho + T_TH - 1) / T_TH;
+    const long ntiles = (long)p.ntx * p.nty * batch;
+    ADA_REQUIRE(ntiles < (1L << 30), ADA_EUNSUPPORTED, "ada_dpt_tail_fwd: too many tiles");
+    p.ntiles = (int)ntiles;
     static std::once_flag once;
     std::call_once(once, []() {
         if (hipFuncSetAttribute((const void*)dpt_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) g_tail_cus = n;
+        if (g_tail_cus <= 0) g_tail_cus = 256;
+        (void)hipGetLastError();
     });
-    hipLaunchKernelGGL(dpt_tail_kernel, dim3((wo + T_TW - 1) / T_TW, (ho + T_TH - 1) / T_TH, batch), dim3(256), smem, (hipStream_t)stream, p);
+    const size_t smem = 2 * (size_t)T_HALO_BYTES + (size_t)p.passes * T_W_BYTES;
+    const int grid = p.ntiles < g_tail_cus ? p.ntiles : g_tail_cus;
+    hipLaunchKernelGGL(dpt_tail_kernel, dim3(grid), dim3(512), smem, (hipStream_t)stream, p);
     return ada_check_launch("ada_dpt_tail_fwd");
 }

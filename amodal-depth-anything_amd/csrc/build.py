@@ -17,6 +17,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["ada_api.hip", "ada_igemm.hip", "ada_attention.hip", "ada_elementwise.hip", "ada_pipeline.hip", "ada_eval.hip", "ada_tail.hip"]
 HEADERS = ["ada_common.h", "ada_igemm_pipe4.inc", os.path.join("..", "..", "include", "ada_hip.h")]
 ARCH = "gfx950"
+# ada_tail.hip: no SLP vectorisation.  Vectorised, the producers' interpolation becomes v_pk_mul_f32 / v_pk_fma_f32 on register pairs
+# gathered with v_mov, and with the other wave of the SIMD issuing MFMAs single elements of the interpolated tile came out wrong (lanes
+# 48-63, reproducible, gone when either wave sleeps or when the packed ops are off) -- profiles/r03_p_fused_tail.txt.
+PER_FILE_FLAGS = {"ada_tail.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -28,7 +32,7 @@ def _hipcc():
 
 def _digest(defines):
     h = hashlib.sha256()
-    for name in SOURCES + HEADERS + ["build.py"]:
+    for name in SOURCES + HEADERS + ["build.py"]:   # build.py itself: flags are part of the digest
         with open(os.path.join(HERE, name), "rb") as f:
             h.update(f.read())
     h.update(" ".join(defines).encode())
@@ -57,7 +61,7 @@ def build(bf16=False, force=False, verbose=True, tag=None, extra_defines=()):
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = common + ["-c", os.path.join(HERE, src), "-o", obj]
+        cmd = common + PER_FILE_FLAGS.get(src, []) + ["-c", os.path.join(HERE, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -66,11 +66,21 @@ LN_EPS = 1e-6
 HEAD_GROUPS = ("proj", "rs0", "rs1", "rs3") + tuple(f"{f}{i}" for f in ("ip", "rn", "rcu", "out") for i in range(4)) + ("oc1", "oc2")
 HEAD_ALIASES = {"tok": ("proj", "rs0", "rs1", "rs3"), "ip": tuple(f"ip{i}" for i in range(4)), "rn": tuple(f"rn{i}" for i in range(4)),
                 "rcu": tuple(f"rcu{i}" for i in range(4)), "out": tuple(f"out{i}" for i in range(4))}
-# ada_dpt_tail_fwd (resize + output_conv2 fused, the up-sampled map never materialised) is built and parity-tested but OFF by default:
-# at ViT-L bs=32 it takes 2.69 ms against 2.18 ms for the resize kernel + tail GEMM it replaces -- with 123 KB of LDS only one 4-wave
-# workgroup fits a CU, so its interpolation phase runs at one wave per SIMD (1.18 ms) and 35 k short-lived workgroups pay their
-# dispatch one after the other (0.57 ms with every phase ablated).  profiles/r02_h_fused_tail_ablation.txt.  ADA_FUSED_TAIL=1 enables it.
-FUSED_TAIL = os.environ.get("ADA_FUSED_TAIL", "0") == "1"
+# ada_dpt_tail_fwd (resize + output_conv2 fused; the up-sampled map "fin" -- 2.2 GB at ViT-L bs=32 -- is neither allocated nor written) is the
+# default tail wherever it applies (fused_tail_applies): 1.26 ms against 2.12 ms for the resize kernel + tail GEMM at ViT-L bs=32
+# (profiles/r03_p_fused_tail.txt).  ADA_FUSED_TAIL=0 selects the two-launch tail everywhere (A/B, and the only path for split-precision "oc2").
+FUSED_TAIL = os.environ.get("ADA_FUSED_TAIL", "1") == "1"
+
+
+def fused_tail_applies(half, halfp, hi, ho, split):
+    """Whether ada_dpt_tail_fwd can take the tail (include/ada_hip.h): single-precision oc2, 64 or 128 (un-padded) channels, and a vertical
+    scale whose 10-row halo tiles span at most 7 source row intervals -- always true for the model's 14 / 8 ratio."""
+    if "oc2" in split or half != halfp or halfp // 64 > 2:
+        return False
+    sy = (hi - 1) / (ho - 1) if ho > 1 else 0.0
+    return int(sy * 9) + 2 <= 7
+
+
 VIT = {
     "vits": dict(dim=384, depth=12, heads=6, ffn="mlp"),
     "vitb": dict(dim=768, depth=12, heads=12, ffn="mlp"),
@@ -376,7 +386,7 @@ class Workspace:
         self.oc1 = lvl0.view(B * self.g296[0] * self.g296[1], half)
         # fused tail (ada_dpt_tail_fwd): resize + output_conv2 in one kernel, the up-sampled map is never materialised.  Needs the
         # single-precision head and a channel count that is already a multiple of 64 (ViT-B / ViT-L heads)
-        self.fused_tail = ("oc2" not in pw_.split) and half == self.halfp and FUSED_TAIL
+        self.fused_tail = FUSED_TAIL and fused_tail_applies(half, self.halfp, self.g296[0], H, pw_.split)
         self.fin = None if self.fused_tail else z(B, H + 2, W + 2, mm("oc2") * self.halfp)
 
 

@@ -223,7 +223,9 @@ int ada_bilinear_fwd(const float* in, int64_t ld_in, int32_t batch, int32_t hi, 
  * DA2/dpt.py:194-195 (F.interpolate + scratch.output_conv2; raw model RAW/dpt.py:148-150) in one kernel; the up-sampled
  * map is never written to memory.  w: op-typed [32, 9 * cp] tap-major (the ada_igemm CONV3 packing), cp = channels padded to
  * a multiple of 64 (weights of pad channels zero; `in` rows must hold cp readable floats: ld_in >= cp).  out: fp32 [B, ho, wo].
- * Up-sampling only (ho >= hi, wo >= wi in practice: the source patch of an 8 x 32 output block must fit in LDS).
+ * Limits (ADA_EUNSUPPORTED otherwise; callers fall back to ada_bilinear_fwd + the EP_TAIL ada_igemm): cp is 64 or 128 (the weights of
+ * every 64-channel pass stay in LDS), and the vertical scale is an up-sampling by at least 1.5 (a 10-row halo tile of the output must
+ * lie within 8 source rows; the model's ratio is always 14 / 8).  Any horizontal scale.
  * ---------------------------------------------------------------------------------------- */
 int ada_dpt_tail_fwd(const float* in, int64_t ld_in, int32_t batch, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
                      int32_t cp, const void* w, const float* bias, const float* tail_w, float tail_b, int32_t tail_act,

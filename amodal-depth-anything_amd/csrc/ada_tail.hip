@@ -35,7 +35,16 @@ constexpr int T_WROW = 9 * T_PIXB;                 // bytes per weight row in LD
 constexpr int T_W_BYTES = T_N * T_WROW;            // 36864 per pass
 constexpr int T_HALO_BYTES = T_HH * T_HW * T_PIXB + 2 * T_PIXB;   // 41216: the fragments of the two discarded columns read 2 pixels on
 constexpr int T_MAX_PASSES = 2;                    // weights of all passes are LDS-resident: 2 * 41216 + 2 * 36864 = 156160 B
-constexpr int T_ROWS = 8;                          // source rows fetched per halo tile: the tile's 10 rows must span <= 7 row intervals
+#ifndef TAIL_PRODUCER_WAVES
+#define TAIL_PRODUCER_WAVES 8
+#endif
+constexpr int T_PW = TAIL_PRODUCER_WAVES;          // producer waves: 4 (one per SIMD, a thread builds all 10 halo rows of its column) or 8 (5 rows each)
+constexpr int T_PH = T_PW / 4;                     // halves of the halo tile, one per group of 4 producer waves
+constexpr int T_HROWS = T_HH / T_PH;               // halo rows per producer thread
+constexpr int T_ROWS = T_PH == 1 ? 8 : 5;          // source rows fetched per thread: its halo rows must span <= T_ROWS - 1 row intervals
+constexpr int T_INFLIGHT = 4 * (T_ROWS - 1);       // fetches that may be outstanding when a row is needed (see interpolate)
+constexpr int T_THREADS = 256 + 64 * T_PW;
+static_assert(T_PW == 4 || T_PW == 8, "4 or 8 producer waves");
 
 struct TailArgs {
     const float* in;
@@ -65,7 +74,7 @@ struct TileAt {
     int b, ty0, tx0;
 };
 
-__global__ __launch_bounds__(512, 1) void dpt_tail_kernel(TailArgs p) {
+__global__ __launch_bounds__(T_THREADS, 1) void dpt_tail_kernel(TailArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const wbuf = smem + 2 * T_HALO_BYTES;
 
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(512, 1) void dpt_tail_kernel(TailArgs p) {
     // k order inside a 64-channel block: chunk c = channels 4c..4c+3 and 32+4c..32+4c+3 (the same permutation on both MFMA operands).
     // A producer lane then fetches two 16-byte pieces that are contiguous with its neighbours': a fetch instruction touches 8 full
     // 128-byte lines instead of 16 half-used ones (the L1 moves whole lines: this halved the producers' fetch time).
-    for (int q = tid; q < p.passes * (T_N * 72); q += 512) {   // chunks of 16 B: (pass, n, tap, chunk)
+    for (int q = tid; q < p.passes * (T_N * 72); q += T_THREADS) {   // chunks of 16 B: (pass, n, tap, chunk)
         const int pass = q / (T_N * 72), r0 = q - pass * (T_N * 72);
         const int n = r0 / 72, rem = r0 - n * 72, t = rem >> 3, c = rem & 7;
         const op_t* g = p.w + (long)n * (9 * p.cp) + t * p.cp + pass * T_CH + 4 * c;
@@ -99,6 +108,7 @@ __global__ __launch_bounds__(512, 1) void dpt_tail_kernel(TailArgs p) {
 
     // ---- producer state: thread (halo column hx, chunk pc) ----
     const int pt = tid & 255;
+    const int half = T_PH == 2 ? __builtin_amdgcn_readfirstlane((tid - 256) >> 8) : 0;   // which T_HROWS rows of the halo tile
     const int hx = pt >> 3, pc = pt & 7;
     const unsigned pdst = (unsigned)(hx * T_PIXB + ((pc ^ ((hx >> 1) & 7)) * 16));
     f32x4 v[T_ROWS][4];
@@ -120,7 +130,8 @@ __global__ __launch_bounds__(512, 1) void dpt_tail_kernel(TailArgs p) {
         x = x < 0 ? 0 : (x > p.wo - 1 ? p.wo - 1 : x);
         const int x0 = (int)(p.sx * (float)x);
         const int x1 = x0 + (x0 < p.wi - 1 ? 1 : 0);
-        const int yv = t.ty0 > 0 ? t.ty0 - 1 : 0;
+        const int yf = t.ty0 - 1 + half * T_HROWS;
+        const int yv = yf < 0 ? 0 : (yf > p.ho - 1 ? p.ho - 1 : yf);
         return Src{(long)x0 * p.ld_in + pass * T_CH + pc * 4, (long)x1 * p.ld_in + pass * T_CH + pc * 4, (int)(p.sy * (float)yv), t.b};
     };
     // The fetches are inline assembly with hand-counted s_waitcnt: written as C++ loads the compiler gives the rows of the next unit fresh
@@ -134,7 +145,7 @@ __global__ __launch_bounds__(512, 1) void dpt_tail_kernel(TailArgs p) {
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[r][2]) : "v"(row + q.o1));
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[r][3]) : "v"(row + q.o1 + 32));
     };
-#define TAIL_WAIT_ROW(r, n) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[r][0]), "+v"(v[r][1]), "+v"(v[r][2]), "+v"(v[r][3]) : "n"(n))
+#define TAIL_WAIT_ROW(r) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[r][0]), "+v"(v[r][1]), "+v"(v[r][2]), "+v"(v[r][3]) : "n"(T_INFLIGHT))
     // Builds unit u's halo tile from the rows in v and, row by row as they are used up, re-issues the fetches of unit u + 1 into the same
     // registers: every row then has a whole unit of interpolation arithmetic plus the barrier wait to land in.  (Fetching all of unit u + 1
     // after unit u is done leaves only the barrier wait: ~2 us of exposed latency per unit, profiles/r03_p_fused_tail.txt.)
@@ -147,11 +158,12 @@ __global__ __launch_bounds__(512, 1) void dpt_tail_kernel(TailArgs p) {
         const int xc = x < 0 ? 0 : (x > p.wo - 1 ? p.wo - 1 : x);
         const float fx = p.sx * (float)xc;
         const float lx1 = fx - (float)(int)fx, lx0 = 1.0f - lx1;
-        const int yv = t.ty0 > 0 ? t.ty0 - 1 : 0;
+        const int yf = t.ty0 - 1 + half * T_HROWS;
+        const int yv = yf < 0 ? 0 : (yf > p.ho - 1 ? p.ho - 1 : yf);
         const int py0 = (int)(p.sy * (float)yv);
         // horizontal interpolation of source row r (computed when the walk below reaches it: the fetched pixels die as they are used)
         // Fetches retire in issue order.  When row r of this unit is needed, the rows after it (4 fetches each) and the rows 0 .. r - 1 of the
-        // next unit, issued since, may still be in flight: always 28 fetches -- the last unit of a workgroup fetches itself again rather
+        // next unit, issued since, may still be in flight: always 4 (T_ROWS - 1) fetches -- the last unit of a workgroup fetches itself again rather
         // than take a second code path (two paths make the row registers phi nodes, which the compiler copies while they are in flight).
         auto hrow = [&](int r, float* h) {
             h[0] = lx0 * v[r][0][0] + lx1 * v[r][2][0]; h[1] = lx0 * v[r][0][1] + lx1 * v[r][2][1];
@@ -162,14 +174,15 @@ __global__ __launch_bounds__(512, 1) void dpt_tail_kernel(TailArgs p) {
         opx8 zero;
 #pragma unroll
         for (int e = 0; e < 8; ++e) zero[e] = (op_t)0.0f;
-        int hy = 0;
-        if (t.ty0 == 0) {   // the row above the image
+        int hy = half * T_HROWS;
+        const int hy_end = hy + T_HROWS;
+        if (yf < 0) {   // the row above the image
             *(opx8*)dst = zero;
             hy = 1;
         }
         float ha[8], hb[8];
 #if !(TAIL_ABL & 4)
-        TAIL_WAIT_ROW(0, 28);
+        TAIL_WAIT_ROW(0);
 #endif
         hrow(0, hb);
         if (!(TAIL_ABL & 4)) fetch_row(nx, 0);
@@ -178,11 +191,11 @@ __global__ __launch_bounds__(512, 1) void dpt_tail_kernel(TailArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) ha[e] = hb[e];
 #if !(TAIL_ABL & 4)
-            TAIL_WAIT_ROW(r + 1, 28);
+            TAIL_WAIT_ROW(r + 1);
 #endif
             hrow(r + 1, hb);
             if (!(TAIL_ABL & 4)) fetch_row(nx, r + 1);
-            while (hy < T_HH) {   // halo rows whose upper source row is py0 + r (wave-uniform: 0, 1 or 2 of them when up-sampling)
+            while (hy < hy_end) {   // halo rows whose upper source row is py0 + r (wave-uniform: 0, 1 or 2 of them when up-sampling)
                 const int y = t.ty0 - 1 + hy;
                 if (y >= p.ho) break;
                 const float fy = p.sy * (float)y;
@@ -196,7 +209,7 @@ __global__ __launch_bounds__(512, 1) void dpt_tail_kernel(TailArgs p) {
                 ++hy;
             }
         }
-        for (; hy < T_HH; ++hy) *(opx8*)(dst + hy * (T_HW * T_PIXB)) = zero;   // rows below the image
+        for (; hy < hy_end; ++hy) *(opx8*)(dst + hy * (T_HW * T_PIXB)) = zero;   // rows below the image
     };
 
     // ---- consumer state: wave w owns output rows 2w, 2w+1 of the tile; fragment f = (row f >> 1, column half f & 1) ----
@@ -313,8 +326,9 @@ extern "C" int ada_dpt_tail_fwd(const float* in, int64_t ld_in, int32_t batch, i
     p.in = in; p.ld_in = ld_in; p.batch = batch; p.hi = hi; p.wi = wi; p.ho = ho; p.wo = wo; p.passes = cp / T_CH;
     p.sy = ho > 1 ? (float)(hi - 1) / (float)(ho - 1) : 0.0f;
     p.sx = wo > 1 ? (float)(wi - 1) / (float)(wo - 1) : 0.0f;
-    // the producers hold T_ROWS source rows per halo tile in registers: the tile's 10 rows may span at most T_ROWS - 1 row intervals
-    ADA_REQUIRE((int)(p.sy * (float)(T_HH - 1)) + 2 <= T_ROWS - 1, ADA_EUNSUPPORTED,
+    // a producer thread holds T_ROWS source rows in registers: its T_HROWS halo rows may span at most T_ROWS - 1 source row intervals.  The
+    // limit is stated for the widest variant (10 rows within 8) so that it does not depend on the build: an up-sampling by at least 1.5
+    ADA_REQUIRE((int)(p.sy * (float)(T_HH - 1)) + 2 <= 7 && (int)(p.sy * (float)(T_HROWS - 1)) + 2 <= T_ROWS - 1, ADA_EUNSUPPORTED,
                 "ada_dpt_tail_fwd: vertical scale %d -> %d is not supported (needs ho >= 1.5 hi; the model's ratio is 14 / 8)", hi, ho);
     p.w = (const op_t*)w; p.cp = cp; p.bias = bias; p.tail_w = tail_w; p.tail_b = tail_b; p.tail_act = tail_act; p.out = out;
     p.ntx = (wo + T_TW - 1) / T_TW;
@@ -332,6 +346,6 @@ extern "C" int ada_dpt_tail_fwd(const float* in, int64_t ld_in, int32_t batch, i
     });
     const size_t smem = 2 * (size_t)T_HALO_BYTES + (size_t)p.passes * T_W_BYTES;
     const int grid = p.ntiles < g_tail_cus ? p.ntiles : g_tail_cus;
-    hipLaunchKernelGGL(dpt_tail_kernel, dim3(grid), dim3(512), smem, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(dpt_tail_kernel, dim3(grid), dim3(T_THREADS), smem, (hipStream_t)stream, p);
     return ada_check_launch("ada_dpt_tail_fwd");
 }

@@ -3,9 +3,9 @@
 # SQ counters (attention row-sum A/B), per-shape table, configs 2 and 5
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-export ADA_COLLECTED="round 3, commit ab64018 + working tree, $(date -u +%Y-%m-%dT%H:%MZ)"
-mkdir -p gpurun_out/r3f
-O=$PWD/gpurun_out/r3f
+export ADA_COLLECTED="round 3, commit 6663667 + working tree, $(date -u +%Y-%m-%dT%H:%MZ)"
+mkdir -p gpurun_out/r3g
+O=$PWD/gpurun_out/r3g
 R=$PWD
 L=$R/amodal-depth-anything_amd/csrc
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -n 4 $O/pytest.log
@@ -24,9 +24,8 @@ cd $R && python3 tools/pmc_traffic.py $F $W && cp profiles/pmc_traffic.json $O/p
 cd /tmp
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -o run -- python3 $R/bench.py --no-cpu-baseline --no-kernel-timer --steps 1 --warmup 1 --repeats 0 > $O/pmc_sq.log 2>&1
 S=$(find $O/pmc_sq -name "*counter_collection.csv" | head -n 1); [ -n "$S" ] && python3 $R/tools/pmc_sq_summary.py $S > $O/pmc_sq_summary.json
-ADA_HIP_LIB=$L/libada_hip_norow.so rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq_norow -o run -- python3 $R/bench.py --no-cpu-baseline --no-kernel-timer --steps 1 --warmup 1 --repeats 0 > $O/pmc_sq_norow.log 2>&1
-S=$(find $O/pmc_sq_norow -name "*counter_collection.csv" | head -n 1); [ -n "$S" ] && python3 $R/tools/pmc_sq_summary.py $S > $O/pmc_sq_summary_norow.json
 cat $O/pmc_sq_summary.json | head -c 1500
 cd $R
+timeout 300 python3 tools/bench_tail.py 2>&1 | grep -v amdgpu > $O/bench_tail.txt; cat $O/bench_tail.txt
 timeout 900 python3 tools/bench_shapes.py --batch 32 --reps 5 2>&1 | grep -v amdgpu > $O/shapes.txt; head -n 8 $O/shapes.txt
 find $O -name "*.db" -size +20M -delete; find $O -name "*counter_collection.csv" -size +20M -delete; du -sh $O

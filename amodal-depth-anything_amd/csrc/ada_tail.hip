@@ -14,7 +14,7 @@
 //     whole unit ahead so they land under the consumers' MFMAs), interpolates horizontally once per source row, then walks down the
 //     halo rows interpolating vertically, and stores operand-typed 16-byte chunks -- zero outside the image (= the convolution's
 //     padding) -- XOR-swizzled so that the consumers' fragment reads are bank-conflict free;
-//   * waves 0-3 (consumers) run the 3 x 3 convolution of the previous unit from the other halo buffer: 9 taps x 2 k-steps of
+//   * waves 0-3 (consumers, 4 rows x 16 columns of the tile each) run the 3 x 3 convolution of the previous unit from the other halo buffer: 9 taps x 2 k-steps of
 //     v_mfma_f32_16x16x32 (a tap is a constant row / column shift of the fragment address) against the weights, which stay resident
 //     in LDS for the life of the workgroup; after the last unit of a tile: bias, ReLU, 32 -> 1 (DPP row reduction), activation, store.
 // One barrier per unit hands the buffers over.
@@ -212,25 +212,26 @@ __global__ __launch_bounds__(T_THREADS, 1) void dpt_tail_kernel(TailArgs p) {
         for (; hy < hy_end; ++hy) *(opx8*)(dst + hy * (T_HW * T_PIXB)) = zero;   // rows below the image
     };
 
-    // ---- consumer state: wave w owns output rows 2w, 2w+1 of the tile; fragment f = (row f >> 1, column half f & 1) ----
-    // A rows are halo pixels (2 * wave + (f >> 1) + dy, 16 * (f & 1) + dx + l15); the 16-byte chunk of a pixel row is XOR-ed with
-    // (column >> 1) & 7, so 16 consecutive pixels of one halo row hit 16 distinct bank slots for any starting column
-    unsigned abase[2][3][2], bbase[2][2];
+    // ---- consumer state: wave w owns output rows 4 (w >> 1) .. + 3 and the column half w & 1 of the tile; fragment f = row in the group ----
+    // A rows are halo pixels (4 (w >> 1) + f + dy, 16 (w & 1) + dx + l15); the 16-byte chunk of a pixel row is XOR-ed with (column >> 1) & 7,
+    // so 16 consecutive pixels of one halo row hit 16 distinct bank slots for any starting column.  The kernel is bound by these fragment
+    // reads (a 32-column GEMM: every MFMA wants a fresh 1 KB), so a wave walks (dx, k half) outermost and reads the six halo rows its
+    // four output rows touch ONCE for all three dy taps: 6 A + 6 B fragments per 24 MFMAs (rows 2 w, 2 w + 1 with dy outermost: 18 per 24).
+    const int rg = (wave & 3) >> 1, ch = wave & 1;
+    unsigned abase[3][2], bbase[2][2];
 #pragma unroll
-    for (int fx = 0; fx < 2; ++fx)
+    for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int ax = 16 * fx + dx + l15;
-                abase[fx][dx][s] = (unsigned)((2 * (wave & 3) * T_HW + ax) * T_PIXB + (((4 * s + q4) ^ ((ax >> 1) & 7)) * 16));
-            }
+        for (int k = 0; k < 2; ++k) {
+            const int ax = 16 * ch + dx + l15;
+            abase[dx][k] = (unsigned)((4 * rg * T_HW + ax) * T_PIXB + (((4 * k + q4) ^ ((ax >> 1) & 7)) * 16));
+        }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int k = 0; k < 2; ++k) {
             const int n = 16 * j + l15;
-            bbase[j][s] = (unsigned)(2 * T_HALO_BYTES + n * T_WROW + (((4 * s + q4) ^ ((n >> 1) & 7)) * 16));
+            bbase[j][k] = (unsigned)(2 * T_HALO_BYTES + n * T_WROW + (((4 * k + q4) ^ ((n >> 1) & 7)) * 16));
         }
     f32x4 acc[4][2];
     float b0 = 0.f, b1 = 0.f, w0 = 0.f, w1 = 0.f;   // fetched by the consumers only: a pending load in a producer wave would be waited for with vmcnt(0) inside its loop
@@ -245,22 +246,40 @@ __global__ __launch_bounds__(T_THREADS, 1) void dpt_tail_kernel(TailArgs p) {
         }
         const char* const ha = smem + (u & 1) * T_HALO_BYTES;
         const char* const wb = smem + pass * T_W_BYTES;
+        // step i = (dx, k half).  The 12 fragment reads of step i + 1 are slotted one behind every second MFMA of step i: left alone the compiler
+        // reads each fragment one or two MFMAs before its use, and the one MFMA-issuing wave of the SIMD sits out the LDS latency some 36 times
+        // per unit.  (Consumers alone, per launch at ViT-L bs=32: 0.82 ms with rows 2w / 2w+1 and dy outermost, 0.75 ms with the six-row reuse,
+        // 0.69 ms with the reads of the next step in one block ahead of the MFMAs, 0.66 ms interleaved -- profiles/r03_p_fused_tail.txt.)
+        opx8 af[2][6], bf[2][3][2];
+        auto read_step = [&](int i, opx8* a, opx8 (*bq)[2]) {
+            const int dx = i >> 1, k = i & 1;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+            for (int hr = 0; hr < 6; ++hr) a[hr] = *(const opx8*)(ha + abase[dx][k] + hr * (T_HW * T_PIXB));
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    opx8 af[4], bf[2];
+                for (int j = 0; j < 2; ++j) bq[dy][j] = *(const opx8*)(wb + bbase[j][k] + (dy * 3 + dx) * T_PIXB);
+        };
+        read_step(0, af[0], bf[0]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) af[f] = *(const opx8*)(ha + abase[f & 1][dx][k] + ((f >> 1) + dy) * (T_HW * T_PIXB));
+        for (int i = 0; i < 6; ++i) {
+            if (i + 1 < 6) read_step(i + 1, af[(i + 1) & 1], bf[(i + 1) & 1]);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bf[j] = *(const opx8*)(wb + bbase[j][k] + (dy * 3 + dx) * T_PIXB);
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int f = 0; f < 4; ++f)
+                for (int f = 0; f < 4; ++f)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[f][j] = mfma16(af[f], bf[j], acc[f][j]);
+                    for (int j = 0; j < 2; ++j) acc[f][j] = mfma16(af[i & 1][f + dy], bf[i & 1][dy][j], acc[f][j]);
+            if (i + 1 < 6) {
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {   // one read of step i + 1 in the shadow of every second MFMA of step i
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (pass != p.passes - 1) return;
         // bias, ReLU, 32 -> 1, activation.  D[4 * q4 + r][l15]: row = pixel inside the 16-pixel fragment, column = output channel
         const TileAt t = tile_of(u);
@@ -270,9 +289,9 @@ __global__ __launch_bounds__(T_THREADS, 1) void dpt_tail_kernel(TailArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 d[r] = row16_sum(__builtin_fmaxf(acc[f][0][r] + b0, 0.0f) * w0 + __builtin_fmaxf(acc[f][1][r] + b1, 0.0f) * w1) + p.tail_b;
-            const int y = t.ty0 + 2 * wave + (f >> 1);
+            const int y = t.ty0 + 4 * rg + f;
             if (l15 < 4 && y < p.ho) {   // lane l15 = r stores pixel r of its quarter: four consecutive floats per 16-lane row
-                const int cx = 16 * (f & 1) + 4 * q4 + l15, x = t.tx0 + cx;
+                const int cx = 16 * ch + 4 * q4 + l15, x = t.tx0 + cx;
                 float o = l15 == 0 ? d[0] : (l15 == 1 ? d[1] : (l15 == 2 ? d[2] : d[3]));
                 if (p.tail_act == ADA_ACT_SIGMOID) o = 1.0f / (1.0f + __expf(-o));
                 else if (p.tail_act == ADA_ACT_RELU) o = __builtin_fmaxf(o, 0.0f);

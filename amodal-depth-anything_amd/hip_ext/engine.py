@@ -67,7 +67,7 @@ HEAD_GROUPS = ("proj", "rs0", "rs1", "rs3") + tuple(f"{f}{i}" for f in ("ip", "r
 HEAD_ALIASES = {"tok": ("proj", "rs0", "rs1", "rs3"), "ip": tuple(f"ip{i}" for i in range(4)), "rn": tuple(f"rn{i}" for i in range(4)),
                 "rcu": tuple(f"rcu{i}" for i in range(4)), "out": tuple(f"out{i}" for i in range(4))}
 # ada_dpt_tail_fwd (resize + output_conv2 fused; the up-sampled map "fin" -- 2.2 GB at ViT-L bs=32 -- is neither allocated nor written) is the
-# default tail wherever it applies (fused_tail_applies): 1.26 ms against 2.12 ms for the resize kernel + tail GEMM at ViT-L bs=32
+# default tail wherever it applies (fused_tail_applies): 1.18 ms against 2.13 ms for the resize kernel + tail GEMM at ViT-L bs=32
 # (profiles/r03_p_fused_tail.txt).  ADA_FUSED_TAIL=0 selects the two-launch tail everywhere (A/B, and the only path for split-precision "oc2").
 FUSED_TAIL = os.environ.get("ADA_FUSED_TAIL", "1") == "1"
 

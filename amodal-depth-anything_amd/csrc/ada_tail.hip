@@ -7,16 +7,18 @@
 // once and re-reads it nine times through L2 from a 32-column GEMM whose A tile is all traffic and no reuse (0.8 ms + 1.3 ms).
 // Here nothing but `in`, the weights and the output touches HBM / L2.
 //
-// Persistent launch, one 8-wave workgroup per CU walking tiles of 8 x 30 output pixels; a tile is processed as `passes` units of 64
-// input channels.  The two waves of a SIMD have different jobs, so that the SIMD's VALU and its matrix pipe work at the same time:
-//   * waves 4-7 (producers) build the unit's 10 x 32 halo tile in LDS: thread (halo column, 8 channels) fetches the two source
-//     pixels of its column for the 8 source rows under the halo straight into registers (fp32, 32 B per pixel and lane, issued a
-//     whole unit ahead so they land under the consumers' MFMAs), interpolates horizontally once per source row, then walks down the
-//     halo rows interpolating vertically, and stores operand-typed 16-byte chunks -- zero outside the image (= the convolution's
-//     padding) -- XOR-swizzled so that the consumers' fragment reads are bank-conflict free;
-//   * waves 0-3 (consumers, 4 rows x 16 columns of the tile each) run the 3 x 3 convolution of the previous unit from the other halo buffer: 9 taps x 2 k-steps of
-//     v_mfma_f32_16x16x32 (a tap is a constant row / column shift of the fragment address) against the weights, which stay resident
-//     in LDS for the life of the workgroup; after the last unit of a tile: bias, ReLU, 32 -> 1 (DPP row reduction), activation, store.
+// Persistent launch, one 12-wave workgroup per CU walking tiles of 8 x 30 output pixels; a tile is processed as `passes` units of 64
+// input channels.  The waves of a SIMD have different jobs, so that its VALU work and its matrix pipe overlap their latencies:
+//   * waves 4-11 (producers, two per SIMD) build the unit's 10 x 32 halo tile in LDS, five rows per group of four waves: thread (halo
+//     column, 8 channels) fetches the two source pixels of its column for the 5 source rows under its halo rows straight into registers
+//     (fp32, two 16-byte pieces per pixel; the fetches of the next unit are re-issued row by row as this unit's rows are used up, so
+//     they land under a whole unit of work), interpolates horizontally once per source row, then walks down its halo rows interpolating
+//     vertically, and stores operand-typed 16-byte chunks -- zero outside the image (= the convolution's padding) -- XOR-swizzled so
+//     that the consumers' fragment reads are bank-conflict free;
+//   * waves 0-3 (consumers, 4 rows x 16 columns of the tile each) run the 3 x 3 convolution of the previous unit from the other halo
+//     buffer: 6 (dx, k half) steps of 24 v_mfma_f32_16x16x32 (a tap is a constant row / column shift of the fragment address) against
+//     the weights, which stay resident in LDS for the life of the workgroup; after the last unit of a tile: bias, ReLU, 32 -> 1 (DPP
+//     row reduction), activation, store.
 // One barrier per unit hands the buffers over.
 #include <mutex>
 #include "ada_common.h"
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(T_THREADS, 1) void dpt_tail_kernel(TailArgs p) {
 
     // ---- the pipeline: during step u the producers build unit u while the consumers convolve unit u - 1 ----
     // Two loops with the same number of barriers (the branch is wave-uniform; s_barrier counts waves, whichever loop they are in): the
-    // producers' 128 registers of pixels in flight are not live in the consumers' code and the other way round.
+    // producers' 80 registers of pixels in flight are not live in the consumers' code and the other way round.
     if (producer) {
         if (nunits > 0 && !(TAIL_ABL & 4)) {
             const Src q = src_of(0);

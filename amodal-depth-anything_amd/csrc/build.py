@@ -21,6 +21,7 @@ ARCH = "gfx950"
 # gathered with v_mov, and with the other wave of the SIMD issuing MFMAs single elements of the interpolated tile came out wrong (lanes
 # 48-63, reproducible, gone when either wave sleeps or when the packed ops are off) -- profiles/r03_p_fused_tail.txt.
 PER_FILE_FLAGS = {"ada_tail.hip": ["-fno-slp-vectorize"]}
+NO_SCRATCH = {"ada_tail.hip"}
 
 
 def _hipcc():
@@ -64,7 +65,19 @@ def build(bf16=False, force=False, verbose=True, tag=None, extra_defines=()):
         cmd = common + PER_FILE_FLAGS.get(src, []) + ["-c", os.path.join(HERE, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        if src in NO_SCRATCH:
+            # kernels that keep in-flight loads in registers managed by hand (inline-asm fetch + hand-counted s_waitcnt): a spill or a
+            # register copy inserted by the compiler between the fetch and its wait would save / move stale data -- refuse such a build
+            res = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, text=True)
+            if res.returncode != 0:
+                sys.stderr.write(res.stderr)
+                raise subprocess.CalledProcessError(res.returncode, cmd)
+            usage = [ln for ln in res.stderr.splitlines() if "ScratchSize" in ln or "VGPRs Spill" in ln]
+            bad = [ln for ln in usage if not ln.rstrip().endswith(": 0 [-Rpass-analysis=kernel-resource-usage]")]
+            if not usage or bad:
+                raise RuntimeError(f"{src}: the kernel must not use scratch / spill registers:\n" + "\n".join(bad or ["no resource-usage remarks found"]))
+        else:
+            subprocess.check_call(cmd)
         return obj
 
     with ThreadPoolExecutor(max_workers=4) as ex:

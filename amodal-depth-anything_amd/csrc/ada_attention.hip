@@ -601,17 +601,26 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_mix(const op_t* __res
         half_exchange(l_run, l_lo, l_hi);
         inv = 1.0f / (l_lo + l_hi);
     }
-    if (q_row < n_tok) {
-        op_t* orow = out + ((long)b * n_tok + q_row) * D + (long)h * HD;
+    // A lane holds d = 32 db + 8 g + 4 hi + e of its query's row: the natural store is eight 8-byte pieces per lane, and that tail is bound by
+    // store ISSUE, not bandwidth (cdna_hip_programming.md T21).  v_permlane32_swap exchanges the upper half-wave of its first operand with the
+    // lower half-wave of its second: for a pair of column groups (g, g + 1) it leaves lanes 0-31 with columns 8 g .. 8 g + 7 and lanes 32-63
+    // with 8 (g + 1) .. + 7 of the same row -- four 16-byte stores per lane instead of eight 8-byte ones.
+    op_t* const orow = out + ((long)b * n_tok + (q_row < n_tok ? q_row : 0)) * D + (long)h * HD;
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
+    for (int db = 0; db < 2; ++db) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                opx4 v4;
+        for (int g = 0; g < 4; g += 2) {
+            opx4 va, vb;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v4[e] = to_op(o[db][g * 4 + e] * inv);
-                *(opx4*)(orow + db * 32 + 8 * g + 4 * hi) = v4;
+            for (int e = 0; e < 4; ++e) {
+                va[e] = to_op(o[db][g * 4 + e] * inv);
+                vb[e] = to_op(o[db][(g + 1) * 4 + e] * inv);
             }
+            u32x2 a = __builtin_bit_cast(u32x2, va), c = __builtin_bit_cast(u32x2, vb);
+            unsigned a0 = a[0], a1 = a[1], c0 = c[0], c1 = c[1];
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a0), "+v"(c0));
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a1), "+v"(c1));
+            if (q_row < n_tok) *(u32x4*)(orow + db * 32 + 8 * (g + hi)) = u32x4{a0, a1, c0, c1};
         }
     }
 }

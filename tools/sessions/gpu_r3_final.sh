@@ -3,12 +3,11 @@
 # SQ counters (attention row-sum A/B), per-shape table, configs 2 and 5
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-export ADA_COLLECTED="round 3, commit 6663667 + working tree, $(date -u +%Y-%m-%dT%H:%MZ)"
-mkdir -p gpurun_out/r3g
-O=$PWD/gpurun_out/r3g
+export ADA_COLLECTED="round 3, commit 7cf5c4f, $(date -u +%Y-%m-%dT%H:%MZ)"
+mkdir -p gpurun_out/r3h
+O=$PWD/gpurun_out/r3h
 R=$PWD
 L=$R/amodal-depth-anything_amd/csrc
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -n 4 $O/pytest.log
 timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q -s -k "golden or batch32" 2>&1 | grep "rel-L1" > $O/parity_vs_reference_goldens.txt; cat $O/parity_vs_reference_goldens.txt
 python bench.py > $O/bench_default_flags.json 2> $O/bench_default_flags.err; tail -c 400 $O/bench_default_flags.json
 timeout 600 python tools/run_configs.py 2>&1 | grep -v amdgpu > $O/other_configs.txt; cat $O/other_configs.txt

@@ -1055,10 +1055,23 @@ static std::atomic<unsigned long long*> g_dbg{nullptr};
 static std::atomic<int> g_force_tile{-1};
 static std::atomic<int> g_variant{0};   // main loop of the 256x256 tile -- 0: by shape (default); 4: single-barrier 8-wave loop; 16: hand-scheduled 4-wave loop
 static std::once_flag g_env_once;
+// A/B switches for kernel experiments: the environment (ADA_IGEMM_TILE / _GROUP / _VARIANT) presets the hooks below ONCE per process, and it
+// does so before the first explicit ada_debug_set_* call as well as before the first launch -- an explicit call always has the last word
+// (a preset applied lazily at the first ada_igemm used to overwrite hooks set before it).
+static void apply_env_presets() {
+    std::call_once(g_env_once, []() {
+        if (const char* e = getenv("ADA_IGEMM_TILE")) g_force_tile.store(atoi(e), std::memory_order_relaxed);
+        if (const char* gr = getenv("ADA_IGEMM_GROUP")) g_group_override.store(atoi(gr), std::memory_order_relaxed);
+        if (const char* va = getenv("ADA_IGEMM_VARIANT")) {
+            const int v = atoi(va);
+            g_variant.store(v >= 16 ? 16 : v >= 4 ? 4 : 0, std::memory_order_relaxed);
+        }
+    });
+}
 // debug hook (not part of the stable ABI): override the tile configuration (-1 = heuristic)
-extern "C" void ada_debug_set_tile(int cfg) { g_force_tile.store(cfg, std::memory_order_relaxed); }
-extern "C" void ada_debug_set_variant(int v) { g_variant.store(v >= 16 ? 16 : v >= 4 ? 4 : 0, std::memory_order_relaxed); }
-extern "C" void ada_debug_set_group(int g) { g_group_override.store(g, std::memory_order_relaxed); }
+extern "C" void ada_debug_set_tile(int cfg) { apply_env_presets(); g_force_tile.store(cfg, std::memory_order_relaxed); }
+extern "C" void ada_debug_set_variant(int v) { apply_env_presets(); g_variant.store(v >= 16 ? 16 : v >= 4 ? 4 : 0, std::memory_order_relaxed); }
+extern "C" void ada_debug_set_group(int g) { apply_env_presets(); g_group_override.store(g, std::memory_order_relaxed); }
 extern "C" int ada_debug_last_tile(void) { return g_last_tile; }
 // debug hook (not part of the stable ABI): device buffer of 8 x u64 per workgroup, or NULL to disable
 extern "C" void ada_debug_set_timestamps(void* dev_buf) { g_dbg.store((unsigned long long*)dev_buf, std::memory_order_relaxed); }
@@ -1173,12 +1186,7 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.group_n = 1;
     d.tiles_m = d.tiles_n = 0;
 
-    // A/B switches for kernel experiments: the environment presets the hooks above once per process
-    std::call_once(g_env_once, []() {
-        if (const char* e = getenv("ADA_IGEMM_TILE")) ada_debug_set_tile(atoi(e));
-        if (const char* gr = getenv("ADA_IGEMM_GROUP")) ada_debug_set_group(atoi(gr));
-        if (const char* va = getenv("ADA_IGEMM_VARIANT")) ada_debug_set_variant(atoi(va));
-    });
+    apply_env_presets();
     const int force = g_force_tile.load(std::memory_order_relaxed);
     d.dbg = g_dbg.load(std::memory_order_relaxed);
     d.variant = g_variant.load(std::memory_order_relaxed);

@@ -14,6 +14,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..", "tools"))
 SOURCES = ["ada_api.hip", "ada_igemm.hip", "ada_attention.hip", "ada_elementwise.hip", "ada_pipeline.hip", "ada_eval.hip", "ada_tail.hip"]
 HEADERS = ["ada_common.h", "ada_igemm_pipe4.inc", os.path.join("..", "..", "include", "ada_hip.h")]
 ARCH = "gfx950"
@@ -24,8 +25,19 @@ ARCH = "gfx950"
 # adjacent scalar adds / muls into) cost more than the two scalar ops they replace when MFMAs are issuing beside them
 # (MI355X_MICROARCH.md): +0.4 % end to end on three interleaved pairs, outputs bit-identical (profiles/r03_w_no_slp_ab.txt).  For the other
 # files (attention, LayerNorm, resizes) the vectoriser helps or is neutral -- attention is 1 % slower without it.
-PER_FILE_FLAGS = {"ada_tail.hip": ["-fno-slp-vectorize"], "ada_igemm.hip": ["-fno-slp-vectorize"]}
+# (-Wno-inline-asm: the generated loop lists m0 among its clobbers -- it rewrites m0 for its LDS-DMA copies and the backend's merging of
+# identical m0 initialisations must see that -- and clang warns about every reserved register in a clobber list.)
+PER_FILE_FLAGS = {"ada_tail.hip": ["-fno-slp-vectorize"], "ada_igemm.hip": ["-fno-slp-vectorize", "-Wno-inline-asm"]}
 NO_SCRATCH = {"ada_tail.hip"}
+# Round 4: the wrong results above were root-caused (profiles/r04_a_tail_inflight_register_root_cause.txt) -- NOT a hardware hazard of packed
+# fp32 beside MFMAs (tools/ubench/pk_f32_beside_mfma.hip: 0 mismatches) but the compiler copying registers that the kernel's inline-asm
+# fetches were still writing: with SLP on, the allocator parks a source row in other registers with v_mov_b64 placed ABOVE the hand-counted
+# s_waitcnt.  The flag only happens to avoid that allocation, so the build now CHECKS the generated ISA (tools/isa_guard.py) and fails if
+#   * any instruction of an ISA_GUARD["inflight"] file touches a VGPR while a load into it may still be outstanding,
+#   * an ISA_GUARD["no_packed_f32"] file contains v_pk_*_f32 (the configuration the kernel was validated in),
+#   * in an ISA_GUARD["agpr_after_pipe4"] file anything but v_accvgpr_read touches an AGPR between the end of the generated 4-wave GEMM
+#     loop and the end of the kernel (the accumulators live in a[0:255] there and the compiler only knows them as clobbered).
+ISA_GUARD = {"inflight": {"ada_tail.hip", "ada_attention.hip"},   # attention: the same construction on the LDS counter (inline-asm ds_read, "+v"-tied lgkmcnt waits) "no_packed_f32": {"ada_tail.hip"}, "agpr_after_pipe4": {"ada_igemm.hip"}}
 
 
 def _hipcc():
@@ -37,7 +49,7 @@ def _hipcc():
 
 def _digest(defines):
     h = hashlib.sha256()
-    for name in SOURCES + HEADERS + ["build.py"]:   # build.py itself: flags are part of the digest
+    for name in SOURCES + HEADERS + ["build.py", os.path.join("..", "..", "tools", "isa_guard.py")]:   # build.py itself: flags are part of the digest
         with open(os.path.join(HERE, name), "rb") as f:
             h.update(f.read())
     h.update((" ".join(defines) + os.environ.get("ADA_EXTRA_FLAGS", "")).encode())
@@ -46,6 +58,32 @@ def _digest(defines):
 
 def lib_path(bf16=False, tag=None):
     return os.path.join(HERE, f"libada_hip_{tag}.so" if tag else "libada_hip_bf16.so" if bf16 else "libada_hip.so")
+
+
+def isa_guard(src, asm_path, kinds):
+    """Checks the device assembly the object was assembled from (-save-temps=obj: the very listing, not a re-compile)."""
+    import isa_guard as G
+    if not os.path.exists(asm_path):
+        raise RuntimeError(f"{src}: device assembly {asm_path} not found -- cannot run the ISA guards")
+    problems = []
+    nk = npipe4 = 0
+    for name, body in G.kernels(open(asm_path).read()).items():
+        if not name.startswith("_Z"):
+            continue
+        nk += 1
+        if "inflight" in kinds:
+            problems += [f"{name} line {no}: `{ins}` touches v{regs} while the load at line {own} may still be writing it"
+                         for no, ins, regs, own in G.check_inflight(body)]
+        if "no_packed_f32" in kinds:
+            problems += [f"{name} line {no}: packed fp32 VALU op `{ins}`" for no, ins in G.check_packed_f32(body)]
+        if "agpr_after_pipe4" in kinds:
+            found = G.check_agpr_after_loop(body)
+            npipe4 += found is not None
+            problems += [f"{name} line {no}: `{ins}` touches an AGPR after the generated main loop" for no, ins in (found or [])]
+    if not nk or ("agpr_after_pipe4" in kinds and not npipe4):
+        raise RuntimeError(f"{src}: no kernel{' with the generated 4-wave loop' if nk else ''} found in {asm_path}")
+    if problems:
+        raise RuntimeError(f"{src}: ISA guard failed ({len(problems)} finding(s), listing {asm_path}):\n  " + "\n  ".join(problems[:20]))
 
 
 def build(bf16=False, force=False, verbose=True, tag=None, extra_defines=()):
@@ -66,7 +104,8 @@ def build(bf16=False, force=False, verbose=True, tag=None, extra_defines=()):
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = common + PER_FILE_FLAGS.get(src, []) + ["-c", os.path.join(HERE, src), "-o", obj]
+        guarded = [kind for kind, files in ISA_GUARD.items() if src in files]
+        cmd = common + PER_FILE_FLAGS.get(src, []) + (["-save-temps=obj"] if guarded else []) + ["-c", os.path.join(HERE, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         if src in NO_SCRATCH:
@@ -82,6 +121,8 @@ def build(bf16=False, force=False, verbose=True, tag=None, extra_defines=()):
                 raise RuntimeError(f"{src}: the kernel must not use scratch / spill registers:\n" + "\n".join(bad or ["no resource-usage remarks found"]))
         else:
             subprocess.check_call(cmd)
+        if guarded:
+            isa_guard(src, os.path.join(objdir, src.replace(".hip", f"-hip-amdgcn-amd-amdhsa-{ARCH}.s")), guarded)
         return obj
 
     with ThreadPoolExecutor(max_workers=4) as ex:

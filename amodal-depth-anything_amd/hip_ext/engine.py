@@ -409,6 +409,10 @@ class _GraphedForward:
         dev = x.device
         self.x = x.detach().contiguous().float().clone()
         self.guide = None if guide is None else guide.detach().contiguous().float().clone()
+        # The captured launches carry raw pointers into this shape's Workspace (allocated by the warm-up forward below, in the ordinary
+        # allocator pool, not the graph's): the graph must keep it alive itself.  Replays never pass through DepthEngine.workspace(), so
+        # the engine's LRU sees a captured shape as idle and may drop its entry -- with this reference that only removes the dict entry.
+        self.ws = eng.workspace(x.shape[0], x.shape[2], x.shape[3], dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):   # warm-up outside the capture: workspace, position table, per-kernel function attributes
@@ -419,6 +423,8 @@ class _GraphedForward:
         # thread-local capture mode: other host threads may keep using the device (a serving process) while this one captures
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = eng._forward(self.x, self.guide, norm)
+        if eng.workspace(x.shape[0], x.shape[2], x.shape[3], dev) is not self.ws:   # cannot happen under the engine lock; never replay a graph over foreign memory
+            raise RuntimeError("workspace changed during graph capture")
         self.lock = threading.Lock()
 
     def __call__(self, x: torch.Tensor, guide: Optional[torch.Tensor]) -> torch.Tensor:
@@ -455,7 +461,7 @@ class DepthEngine:
         ws = self._ws.get(key)
         if ws is None:
             while len(self._ws) >= max(1, MAX_WORKSPACES):
-                self._ws.popitem(last=False)      # least recently used shape; a captured graph keeps its own workspace alive
+                self._ws.popitem(last=False)      # least recently used shape; a captured graph holds its own reference (_GraphedForward.ws)
             ws = Workspace(self.w, B, H, W, device)
             self._ws[key] = ws
         else:

@@ -111,11 +111,54 @@ def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int = 0, tail: str = "no
     return sd
 
 
-def make_inputs(batch: int, height: int = 518, width: int = 518, seed: int = 0, device="cpu"):
-    """Synthetic inputs of SURVEY.md §8(d): RGB in [0,1), rectangular amodal mask (+-1),
-    smooth-ish observation in [-1,1].  Returns (x, guide_rgb, guide_mask, observation)."""
+def _structured_inputs(batch: int, height: int, width: int, g: torch.Generator):
+    """Image-like inputs (what the reference's caller actually feeds, infer.py:17-27,88-93): smooth low-frequency RGB with a little
+    fine texture, a filled-ellipse amodal mask, and an observation that is a smooth depth-like map min-max normalised to [-1, 1]
+    (infer.py:22 ``(d - d.min()) / (d.max() - d.min())`` then ``* 2 - 1``)."""
+    yy = torch.linspace(0.0, 1.0, height).view(1, 1, height, 1)
+    xx = torch.linspace(0.0, 1.0, width).view(1, 1, 1, width)
+
+    def smooth(channels):   # sum of four low-frequency plane waves + a linear ramp per channel
+        f = torch.zeros(batch, channels, height, width)
+        for _ in range(4):
+            fy = torch.rand(batch, channels, 1, 1, generator=g) * 3.0
+            fx = torch.rand(batch, channels, 1, 1, generator=g) * 3.0
+            ph = torch.rand(batch, channels, 1, 1, generator=g) * 6.2831853
+            amp = 0.15 + 0.25 * torch.rand(batch, channels, 1, 1, generator=g)
+            f = f + amp * torch.sin(6.2831853 * (fy * yy + fx * xx) + ph)
+        ry = torch.rand(batch, channels, 1, 1, generator=g) - 0.5
+        rx = torch.rand(batch, channels, 1, 1, generator=g) - 0.5
+        return f + ry * yy + rx * xx
+
+    def rgb():
+        tex = 0.03 * (torch.rand(batch, 3, height, width, generator=g) - 0.5)   # sensor-noise-sized texture
+        return (0.5 + 0.6 * smooth(3) + tex).clamp_(0.0, 1.0)
+
+    x, guide_rgb = rgb(), rgb()
+    d = smooth(1)
+    lo = d.amin(dim=(2, 3), keepdim=True)
+    hi = d.amax(dim=(2, 3), keepdim=True)
+    obs = (d - lo) / (hi - lo) * 2 - 1
+    mask = -torch.ones(batch, 1, height, width)
+    for b in range(batch):
+        cy = 0.25 + 0.5 * float(torch.rand(1, generator=g))
+        cx = 0.25 + 0.5 * float(torch.rand(1, generator=g))
+        ay = 0.08 + 0.25 * float(torch.rand(1, generator=g))
+        ax = 0.08 + 0.25 * float(torch.rand(1, generator=g))
+        inside = ((yy - cy) / ay) ** 2 + ((xx - cx) / ax) ** 2 <= 1.0
+        mask[b][inside[0]] = 1.0
+    return x, guide_rgb, mask, obs
+
+
+def make_inputs(batch: int, height: int = 518, width: int = 518, seed: int = 0, device="cpu", style: str = "noise"):
+    """Synthetic inputs of SURVEY.md §8(d).  ``style="noise"``: i.i.d. uniform RGB in [0,1), rectangular amodal mask (+-1), i.i.d. uniform
+    observation in [-1,1].  ``style="structured"``: image-like inputs (_structured_inputs).  Returns (x, guide_rgb, guide_mask, observation)."""
+    assert style in ("noise", "structured"), style
     g = torch.Generator(device="cpu")
     g.manual_seed(1000003 * seed + 17)
+    if style == "structured":
+        x, guide_rgb, mask, obs = _structured_inputs(batch, height, width, g)
+        return x.to(device), guide_rgb.to(device), mask.to(device), obs.to(device)
     x = torch.rand(batch, 3, height, width, generator=g)
     guide_rgb = torch.rand(batch, 3, height, width, generator=g)
     obs = torch.rand(batch, 1, height, width, generator=g) * 2 - 1

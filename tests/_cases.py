@@ -64,7 +64,7 @@ def synth_state_dict(model, meta=None, seed=None):
 
 def case_inputs(case, seed=None):
     """Inputs of a fixture case: make_inputs(B, H, W, seed), restricted to case["take"] when present."""
-    x, grgb, mask, obs = make_inputs(case["B"], case["H"], case["W"], case.get("seed", 0) if seed is None else seed)
+    x, grgb, mask, obs = make_inputs(case["B"], case["H"], case["W"], case.get("seed", 0) if seed is None else seed, style=case.get("inputs", "noise"))
     if "take" in case:
         idx = torch.tensor(case["take"])
         x, grgb, mask, obs = x[idx], grgb[idx], mask[idx], obs[idx]

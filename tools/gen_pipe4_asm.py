@@ -156,7 +156,7 @@ def main():
     # the zero-filling copies past the last k-tile must not land in the epilogue's LDS slabs; MFMA results need wait states before v_accvgpr_read
     L += [q("s_waitcnt vmcnt(0)"), q("s_nop 15"), q("s_nop 15")]
 
-    clob = [f'"v{i}"' for i in range(136)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(84, 94)] + ['"scc"', '"memory"']
+    clob = [f'"v{i}"' for i in range(136)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(84, 94)] + ['"m0"', '"scc"', '"memory"']
     ins = ['[ra] "s"(ra)', '[rb] "s"(rb)'] + [f'[ao{i}] "v"(ao[{i}])' for i in range(8)] + [f'[bo{i}] "v"(bo[{i}])' for i in range(8)] + \
           ['[abase] "v"(abase)', '[bbase] "v"(bbase)', '[m0s0] "s"(m0s0)', '[sa0] "s"(sa0)', '[sa1] "s"(sa1)', '[sb1] "s"(sb1)', '[sa2] "s"(sa2)',
            '[nk] "s"(nk)', '[period] "s"(period)', '[cnt] "s"(cnt)', '[jump] "s"(jump)']

@@ -70,6 +70,18 @@ struct LnArgs {
     float* out_f32;
     long ld_f32;
     int split_seg;
+    // second normalised output of the same rows (same statistics, its own gain / bias): rows are taken in groups of out2_group, the first
+    // out2_skip rows of each group are left out and the rest compacted -- the tap LayerNorm (cls token dropped) rides on the next block's LN1
+    const float* weight2;
+    const float* bias2;
+    op_t* out2;
+    long ld2;
+    int out2_group, out2_skip, split_seg2;
+    FastDiv dOut2Group;
+    // input rows are fine-grid pixels of a sub-pixel convolution's [coarse pixel, s*s*dim] output (unshuffle_s = s > 0; map_h / map_w = fine grid)
+    int unshuffle_s;
+    FastDiv dUnS;
+    const float* tap_bias;   // [s*s*dim, 9]: bias contribution of coarse tap t to column (phase, c); subtracted where the tap falls outside the grid
 };
 
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
@@ -84,6 +96,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     }
     const float4* src = (const float4*)(p.in + in_row * p.ld_in);
     const int nchunk = p.dim >> 2;
+    // sub-pixel input: output row ro is fine pixel (b, Y, X); its dim values are columns [phase * dim, (phase + 1) * dim) of coarse row (b, Y / s, X / s).
+    // On the outermost ring of the fine grid some coarse taps fall into the zero border, where the merged convolution must not see the
+    // transposed conv's bias either: their share of the (interior) bias the GEMM added is taken out again here.
+    unsigned ring = 0;          // bit t: coarse tap t is outside the grid for this pixel
+    const float* tapb = nullptr;
+    if (p.unshuffle_s > 0) {
+        uint32_t b, rem, Y, X, cy, py, cx, px;
+        fast_divmod((uint32_t)ro, p.dMapHW, b, rem);
+        fast_divmod(rem, p.dMapW, Y, X);
+        fast_divmod(Y, p.dUnS, cy, py);
+        fast_divmod(X, p.dUnS, cx, px);
+        const int ss = p.unshuffle_s, ch = p.map_h / ss, cw = p.map_w / ss;
+        const int phase = (int)(py * ss + px);
+        src = (const float4*)(p.in + (((long)b * ch + cy) * cw + cx) * p.ld_in + (long)phase * p.dim);
+        if (p.tap_bias) {
+            if (Y == 0) ring |= 0x007u;
+            if ((int)Y == p.map_h - 1) ring |= 0x1c0u;
+            if (X == 0) ring |= 0x049u;
+            if ((int)X == p.map_w - 1) ring |= 0x124u;
+            tapb = p.tap_bias + (long)phase * p.dim * 9;
+        }
+    }
     float4 v[LN_MAX_CHUNKS];
     float s = 0.0f;
 #pragma unroll
@@ -91,6 +125,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
             v[i] = src[c];
+            if (ring) {   // wave-uniform, ~2 % of the rows
+                const float* tb = tapb + (long)c * 36;
+                for (int t = 0; t < 9; ++t)
+                    if ((ring >> t) & 1u) { v[i].x -= tb[t]; v[i].y -= tb[9 + t]; v[i].z -= tb[18 + t]; v[i].w -= tb[27 + t]; }
+            }
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         } else {
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -127,6 +166,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
             }
             if (p.out_f32) ((float4*)(p.out_f32 + (long)ro * p.ld_f32))[c] = y;
             if (p.out_op) store_op4_split(p.out_op + orow * p.ld_op, c, y, p.split_seg);
+        }
+    }
+    if (p.out2) {
+        uint32_t g, w;
+        fast_divmod((uint32_t)ro, p.dOut2Group, g, w);
+        if ((int)w < p.out2_skip) return;
+        op_t* dst = p.out2 + ((long)g * (p.out2_group - p.out2_skip) + (w - p.out2_skip)) * p.ld2;
+        const float4* w24 = (const float4*)p.weight2;
+        const float4* b24 = (const float4*)p.bias2;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                const float4 w = w24[c], bb = b24[c];
+                float4 y;
+                y.x = (v[i].x - mean) * rstd * w.x + bb.x;
+                y.y = (v[i].y - mean) * rstd * w.y + bb.y;
+                y.z = (v[i].z - mean) * rstd * w.z + bb.z;
+                y.w = (v[i].w - mean) * rstd * w.w + bb.w;
+                store_op4_split(dst, c, y, p.split_seg2);
+            }
         }
     }
 }
@@ -398,30 +458,57 @@ extern "C" int ada_rowstats_finalize(const float* partials, int32_t rows, int32_
     return ada_check_launch("ada_rowstats_finalize");
 }
 
+extern "C" int ada_layernorm_ex(const ada_layernorm_args* a, void* stream) {
+    ADA_REQUIRE(a != nullptr, ADA_EINVAL, "ada_layernorm: null args");
+    const int rows_out = a->rows_out, dim = a->dim;
+    ADA_REQUIRE(a->in && a->weight && a->bias, ADA_EINVAL, "ada_layernorm_fwd: null pointer");
+    ADA_REQUIRE(a->out_op || a->out_f32 || a->out2_op, ADA_EINVAL, "ada_layernorm_fwd: no output buffer");
+    ADA_REQUIRE(rows_out > 0 && dim > 0, ADA_EINVAL, "ada_layernorm_fwd: bad shape rows=%d dim=%d", rows_out, dim);
+    ADA_REQUIRE(dim % 4 == 0 && dim <= LN_MAX_CHUNKS * 256, ADA_EUNSUPPORTED, "ada_layernorm_fwd: dim=%d must be a multiple of 4 and <= 1536", dim);
+    ADA_REQUIRE(a->ld_in % 4 == 0 && (!a->out_f32 || a->ld_f32 % 4 == 0) && (!a->out_op || a->ld_op % 4 == 0), ADA_EINVAL, "ada_layernorm_fwd: leading dims must be multiples of 4");
+    ADA_REQUIRE(a->group_in == 0 || (a->skip >= 0 && a->skip < a->group_in), ADA_EINVAL, "ada_layernorm_fwd: bad group/skip");
+    ADA_REQUIRE(a->map_op == ADA_MAP_PLAIN || a->map_op == ADA_MAP_PAD, ADA_EUNSUPPORTED, "ada_layernorm_fwd: map must be PLAIN or PAD");
+    if (a->out_op && a->map_op == ADA_MAP_PAD) ADA_REQUIRE(a->map_h > 0 && a->map_w > 0 && rows_out % (a->map_h * a->map_w) == 0, ADA_EINVAL, "ada_layernorm_fwd: bad PAD grid");
+    ADA_REQUIRE((long)rows_out < (1L << 24), ADA_EUNSUPPORTED, "ada_layernorm_fwd: too many rows");
+    LnArgs p;
+    p.in = a->in; p.ld_in = a->ld_in; p.rows_out = rows_out; p.dim = dim; p.group_in = a->group_in; p.skip = a->skip;
+    p.dGroupOut = make_fastdiv(a->group_in > 0 ? a->group_in - a->skip : 1);
+    p.weight = a->weight; p.bias = a->bias; p.eps = a->eps;
+    p.out_op = (op_t*)a->out_op; p.ld_op = a->ld_op; p.map_op = a->map_op; p.map_h = a->map_h; p.map_w = a->map_w;
+    p.dMapW = make_fastdiv(a->map_w > 0 ? a->map_w : 1);
+    p.dMapHW = make_fastdiv(a->map_h > 0 && a->map_w > 0 ? a->map_h * a->map_w : 1);
+    p.relu = a->relu; p.out_f32 = a->out_f32; p.ld_f32 = a->ld_f32;
+    ADA_REQUIRE(a->split_seg == 0 || (a->out_op && a->split_seg >= dim && a->split_seg % 4 == 0 && a->ld_op >= 2L * a->split_seg), ADA_EINVAL, "ada_layernorm_fwd: bad split_seg=%d for dim=%d ld_op=%ld", a->split_seg, dim, (long)a->ld_op);
+    p.split_seg = a->split_seg;
+    p.weight2 = a->weight2; p.bias2 = a->bias2; p.out2 = (op_t*)a->out2_op; p.ld2 = a->ld2_op;
+    p.out2_group = a->out2_group > 0 ? a->out2_group : 1; p.out2_skip = a->out2_group > 0 ? a->out2_skip : 0; p.split_seg2 = a->split_seg2;
+    p.dOut2Group = make_fastdiv((uint32_t)p.out2_group);
+    if (a->out2_op) {
+        ADA_REQUIRE(a->weight2 && a->bias2 && a->ld2_op % 4 == 0 && a->group_in == 0 && a->unshuffle_s == 0, ADA_EINVAL, "ada_layernorm: the second output needs its own gain / bias, ld2 %% 4 == 0 and plainly ordered input rows");
+        ADA_REQUIRE(a->out2_group == 0 || (a->out2_skip >= 0 && a->out2_skip < a->out2_group && rows_out % a->out2_group == 0), ADA_EINVAL, "ada_layernorm: bad out2 group/skip");
+        ADA_REQUIRE(a->split_seg2 == 0 || (a->split_seg2 >= dim && a->split_seg2 % 4 == 0 && a->ld2_op >= 2L * a->split_seg2), ADA_EINVAL, "ada_layernorm: bad split_seg2");
+    }
+    p.unshuffle_s = a->unshuffle_s; p.dUnS = make_fastdiv(a->unshuffle_s > 0 ? a->unshuffle_s : 1); p.tap_bias = a->tap_bias;
+    if (a->unshuffle_s != 0) {
+        ADA_REQUIRE(a->unshuffle_s > 0 && a->unshuffle_s <= 4 && a->group_in == 0 && a->map_h > 0 && a->map_w > 0 && a->map_h % a->unshuffle_s == 0 &&
+                    a->map_w % a->unshuffle_s == 0 && rows_out % (a->map_h * a->map_w) == 0 && a->ld_in >= (long)a->unshuffle_s * a->unshuffle_s * dim, ADA_EINVAL,
+                    "ada_layernorm: sub-pixel input needs s in 1..4, a fine grid map_h x map_w divisible by s and ld_in >= s*s*dim");
+    } else {
+        ADA_REQUIRE(!a->tap_bias, ADA_EINVAL, "ada_layernorm: tap_bias without unshuffle_s");
+    }
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows_out + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    return ada_check_launch("ada_layernorm_fwd");
+}
+
 extern "C" int ada_layernorm_fwd(const float* in, int64_t ld_in, int32_t rows_out, int32_t dim, int32_t group_in, int32_t skip,
                                  const float* weight, const float* bias, float eps, void* out_op, int64_t ld_op, int32_t map_op,
                                  int32_t map_h, int32_t map_w, int32_t relu, float* out_f32, int64_t ld_f32, int32_t split_seg, void* stream) {
-    ADA_REQUIRE(in && weight && bias, ADA_EINVAL, "ada_layernorm_fwd: null pointer");
-    ADA_REQUIRE(out_op || out_f32, ADA_EINVAL, "ada_layernorm_fwd: no output buffer");
-    ADA_REQUIRE(rows_out > 0 && dim > 0, ADA_EINVAL, "ada_layernorm_fwd: bad shape rows=%d dim=%d", rows_out, dim);
-    ADA_REQUIRE(dim % 4 == 0 && dim <= LN_MAX_CHUNKS * 256, ADA_EUNSUPPORTED, "ada_layernorm_fwd: dim=%d must be a multiple of 4 and <= 1536", dim);
-    ADA_REQUIRE(ld_in % 4 == 0 && (!out_f32 || ld_f32 % 4 == 0) && (!out_op || ld_op % 4 == 0), ADA_EINVAL, "ada_layernorm_fwd: leading dims must be multiples of 4");
-    ADA_REQUIRE(group_in == 0 || (skip >= 0 && skip < group_in), ADA_EINVAL, "ada_layernorm_fwd: bad group/skip");
-    ADA_REQUIRE(map_op == ADA_MAP_PLAIN || map_op == ADA_MAP_PAD, ADA_EUNSUPPORTED, "ada_layernorm_fwd: map must be PLAIN or PAD");
-    if (out_op && map_op == ADA_MAP_PAD) ADA_REQUIRE(map_h > 0 && map_w > 0 && rows_out % (map_h * map_w) == 0, ADA_EINVAL, "ada_layernorm_fwd: bad PAD grid");
-    ADA_REQUIRE((long)rows_out < (1L << 24), ADA_EUNSUPPORTED, "ada_layernorm_fwd: too many rows");
-    LnArgs p;
-    p.in = in; p.ld_in = ld_in; p.rows_out = rows_out; p.dim = dim; p.group_in = group_in; p.skip = skip;
-    p.dGroupOut = make_fastdiv(group_in > 0 ? group_in - skip : 1);
-    p.weight = weight; p.bias = bias; p.eps = eps;
-    p.out_op = (op_t*)out_op; p.ld_op = ld_op; p.map_op = map_op; p.map_h = map_h; p.map_w = map_w;
-    p.dMapW = make_fastdiv(map_w > 0 ? map_w : 1);
-    p.dMapHW = make_fastdiv(map_h > 0 && map_w > 0 ? map_h * map_w : 1);
-    p.relu = relu; p.out_f32 = out_f32; p.ld_f32 = ld_f32;
-    ADA_REQUIRE(split_seg == 0 || (out_op && split_seg >= dim && split_seg % 4 == 0 && ld_op >= 2L * split_seg), ADA_EINVAL, "ada_layernorm_fwd: bad split_seg=%d for dim=%d ld_op=%ld", split_seg, dim, (long)ld_op);
-    p.split_seg = split_seg;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows_out + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
-    return ada_check_launch("ada_layernorm_fwd");
+    ada_layernorm_args a = {};
+    a.in = in; a.ld_in = ld_in; a.rows_out = rows_out; a.dim = dim; a.group_in = group_in; a.skip = skip;
+    a.weight = weight; a.bias = bias; a.eps = eps;
+    a.out_op = out_op; a.ld_op = ld_op; a.map_op = map_op; a.map_h = map_h; a.map_w = map_w; a.relu = relu;
+    a.out_f32 = out_f32; a.ld_f32 = ld_f32; a.split_seg = split_seg;
+    return ada_layernorm_ex(&a, stream);
 }
 
 extern "C" int ada_patchify(const float* x, const float* guide, int32_t batch, int32_t cg, int32_t height, int32_t width,

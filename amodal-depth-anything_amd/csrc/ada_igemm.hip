@@ -85,6 +85,8 @@ struct IgemmDev {
     int rowstat_groups;       // N / 64
     int split_seg;   // > 0: the op-typed output is written as [hi | lo] in two column segments of this width (split precision)
     int a_dup_seg;   // > 0: the A operand is a [hi | lo] split tensor contracted as (hi, lo, hi) against [w_hi | w_hi | w_lo] weights
+    int tap_cols;    // CONV3, > 0: the N columns come in blocks of tap_cols ("phases" of a sub-pixel convolution) that use only some of the 9 taps
+    unsigned long long tap_bits[3];   // 9-bit tap masks of up to 16 blocks, seven per word
     FastDiv dShC, dShS;
     const float* tail_w;
     float tail_b;
@@ -381,7 +383,26 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][ab][r] = 0.0f;
 
-    const int nk = p.K / BK;
+    // Sub-pixel convolutions (a stride-s transposed conv merged with the 3x3 conv that follows it, see ada_igemm_args.tap_cols): each block of
+    // tap_cols output columns is one output phase and touches only 1, 2 or 4 of the 9 taps of the coarse grid -- the other weight blocks are
+    // structurally zero.  The k-walk of this N-tile visits the union of its phases' taps only.
+    unsigned long long taps_packed = 0x876543210ull;   // active taps in walk order, 4 bits each
+    int ntaps = 9;
+    if (p.a_mode != ADA_A_PLAIN && p.tap_cols > 0) {
+        const int first = n0 / p.tap_cols, lastn = (n0 + BN < p.N ? n0 + BN : p.N) - 1;
+        const int last = lastn / p.tap_cols;
+        unsigned mask = 0;
+        for (int ph = first; ph <= last; ++ph) {
+            const int wi = ph >= 14 ? 2 : (ph >= 7 ? 1 : 0);
+            mask |= (unsigned)(p.tap_bits[wi] >> (9 * (ph - 7 * wi))) & 0x1ffu;
+        }
+        mask = (unsigned)__builtin_amdgcn_readfirstlane((int)mask);
+        taps_packed = 0;
+        ntaps = 0;
+        for (int t = 0; t < 9; ++t)
+            if ((mask >> t) & 1u) taps_packed |= (unsigned long long)t << (4 * ntaps++);
+    }
+    const int nk = p.a_mode == ADA_A_PLAIN ? p.K / BK : ntaps * cps;
     if constexpr (PIPE4) {
         // everything between here and the epilogue's first dump() is the generated asm: fragments in v[0:127], accumulators in a[0:255]
         const int l15 = lane & 15, q4 = lane >> 4;
@@ -412,9 +433,28 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
         pipe4_main_loop(a_rs, b_rs, a_off, b_off, abase, bbase, m0s0, (unsigned)(a0o * 2), nk > 1 ? (unsigned)(a1o * 2) : OOB, nk > 1 ? 128u : OOB,
                         (unsigned)(a2o * 2), (unsigned)nk, period, cnt, jump);
     } else {
+    // Offsets of the next slab to stage.  Plain operands walk k-step j directly; a 3x3 conv walks (active tap, k-step inside the tap) with two
+    // scalar counters (no division per k-step), the taps taken from taps_packed.
+    int w_j = 0, w_ti = 0, w_kc = 0;
+    auto next_offsets = [&](long& aoff, long& boff) {
+        if (p.a_mode == ADA_A_PLAIN) {
+            slab_offsets(w_j, aoff, boff);
+            ++w_j;
+            return;
+        }
+        const int tap = (int)((taps_packed >> (4 * w_ti)) & 15ull);
+        const int kca = (sps > 0 && w_kc >= 2 * sps) ? w_kc - 2 * sps : w_kc;
+        const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
+        aoff = ((long)dy * p.Wp + dx) * p.lda + (long)kca * BK;
+        boff = ((long)tap * cps + w_kc) * BK;
+        if (++w_kc == cps) {
+            w_kc = 0;
+            ++w_ti;
+        }
+    };
     {
         long aoff, boff;
-        slab_offsets(0, aoff, boff);
+        next_offsets(aoff, boff);
         stage_part(0, aoff, boff, -1);
     }
     {
@@ -442,7 +482,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             const bool late = (NWAVES == 8) && wave < 4;
             const bool more = kt + 1 < nk;
             long aoff = 0, boff = 0;
-            if (more) slab_offsets(kt + 1, aoff, boff);
+            if (more) next_offsets(aoff, boff);
             // (Spreading the 8 copies of a wave over the MFMAs of "its" k half -- two behind every 8 MFMAs, order pinned with sched_barrier, the
             // thing that was worth 20 % in the 4-wave loop -- makes THIS loop slower: fc1 +10 %, fc2 +14 %, 8192^3 +20 %; the partner wave on the
             // SIMD already covers a burst, and the pins cost the compiler its own schedule.  profiles/r03_i_gemm_4wave_asm_loop.txt)
@@ -1004,7 +1044,7 @@ static inline double tile_time(long M, long N, int bm, int bn, int occ, double e
 // main loop of the 256x256 tile: variant 16 forces the hand-scheduled 4-wave loop, 4 the single-barrier 8-wave loop; 0 (default) picks the
 // 4-wave loop where its main loop outweighs its slower prologue / epilogue (measured: k-loops of >= 128 k-tiles)
 // (its scalar A-offset counters assume a monotonic walk: a split operand, whose third k segment re-reads the first, stays on the 8-wave loop)
-static inline bool use_pipe4(const IgemmDev& d) { return d.a_dup_seg == 0 && (d.variant >= 16 || (d.variant == 0 && d.K >= 8192)); }
+static inline bool use_pipe4(const IgemmDev& d) { return d.a_dup_seg == 0 && d.tap_cols == 0 && (d.variant >= 16 || (d.variant == 0 && d.K >= 8192)); }
 
 template <int EPI>
 int launch_epi(IgemmDev& d, hipStream_t s, int force) {
@@ -1152,6 +1192,12 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
         const int cols = shuffle ? a->shuffle_c : a->N;
         ADA_REQUIRE(cols <= a->split_seg && a->ldo_op >= 2L * a->split_seg, ADA_EINVAL, "ada_igemm: split_seg=%d too small for %d columns / ldo_op=%ld", a->split_seg, cols, (long)a->ldo_op);
     }
+    if (a->tap_cols != 0) {
+        ADA_REQUIRE(a->a_mode == ADA_A_CONV3 && a->tap_cols > 0 && a->N % a->tap_cols == 0 && a->N / a->tap_cols <= 16, ADA_EINVAL,
+                    "ada_igemm: tap_cols=%d needs a CONV3 operand and N = (1..16) * tap_cols (N=%d)", a->tap_cols, a->N);
+        for (int i = 0; i < a->N / a->tap_cols; ++i)
+            ADA_REQUIRE(a->tap_mask[i] != 0 && a->tap_mask[i] < 512, ADA_EINVAL, "ada_igemm: tap_mask[%d]=0x%x must name 1..9 of the taps", i, (unsigned)a->tap_mask[i]);
+    }
     if ((a->out_f32 && a->map_f32 == ADA_MAP_TOKEN) || (a->out_op && a->map_op == ADA_MAP_TOKEN)) {
         ADA_REQUIRE(a->map_h > 0 && a->M % a->map_h == 0, ADA_EINVAL, "ada_igemm: TOKEN map needs map_h = patches per image");
     }
@@ -1177,6 +1223,10 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.shuffle_s = a->shuffle_s; d.shuffle_c = a->shuffle_c;
     d.split_seg = a->split_seg;
     d.a_dup_seg = a->a_dup_seg;
+    d.tap_cols = a->tap_cols;
+    d.tap_bits[0] = d.tap_bits[1] = d.tap_bits[2] = 0;
+    if (a->tap_cols > 0)
+        for (int i = 0; i < a->N / a->tap_cols; ++i) d.tap_bits[i / 7] |= (unsigned long long)a->tap_mask[i] << (9 * (i % 7));
     d.ln_stats = a->ln_stats; d.ln_colsum = a->ln_colsum;
     d.rowstat_out = a->rowstat_out; d.rowstat_groups = a->N / 64;
     d.dShC = make_fastdiv(a->shuffle_c > 0 ? a->shuffle_c : 1);

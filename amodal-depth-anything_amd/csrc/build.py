@@ -37,7 +37,8 @@ NO_SCRATCH = {"ada_tail.hip"}
 #   * an ISA_GUARD["no_packed_f32"] file contains v_pk_*_f32 (the configuration the kernel was validated in),
 #   * in an ISA_GUARD["agpr_after_pipe4"] file anything but v_accvgpr_read touches an AGPR between the end of the generated 4-wave GEMM
 #     loop and the end of the kernel (the accumulators live in a[0:255] there and the compiler only knows them as clobbered).
-ISA_GUARD = {"inflight": {"ada_tail.hip", "ada_attention.hip"},   # attention: the same construction on the LDS counter (inline-asm ds_read, "+v"-tied lgkmcnt waits) "no_packed_f32": {"ada_tail.hip"}, "agpr_after_pipe4": {"ada_igemm.hip"}}
+# (ada_attention.hip has the same construction on the LDS counter -- inline-asm ds_read into C++ variables, "+v"-tied lgkmcnt waits -- and is held to the same rule)
+ISA_GUARD = {"inflight": {"ada_tail.hip", "ada_attention.hip"}, "no_packed_f32": {"ada_tail.hip"}, "agpr_after_pipe4": {"ada_igemm.hip"}}
 
 
 def _hipcc():

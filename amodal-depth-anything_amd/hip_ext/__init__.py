@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint16, c_void_p
 from typing import Optional
 
 import torch
@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
 # --- constants mirrored from include/ada_hip.h ------------------------------------------------
-ABI_VERSION = 4
+ABI_VERSION = 5
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 A_PLAIN, A_CONV3 = 0, 1
 MAP_PLAIN, MAP_PAD, MAP_TOKEN, MAP_SHUFFLE = 0, 1, 2, 3
@@ -28,7 +28,7 @@ ACT_NONE, ACT_SIGMOID, ACT_RELU = 0, 1, 2
 
 EXPORTS = (
     "ada_abi_version", "ada_operand_dtype", "ada_last_error", "ada_igemm", "ada_attention_fwd",
-    "ada_rowstats_finalize", "ada_pos_embed_resize", "ada_layernorm_fwd", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
+    "ada_rowstats_finalize", "ada_pos_embed_resize", "ada_layernorm_fwd", "ada_layernorm_ex", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
     "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd", "ada_dpt_tail_fwd",
     "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
     "ada_debug_set_timestamps", "ada_debug_set_attention_variant", "ada_debug_count_saturated",
@@ -53,6 +53,19 @@ class IgemmArgs(ctypes.Structure):
         ("map_h", c_int32), ("map_w", c_int32), ("shuffle_s", c_int32), ("shuffle_c", c_int32),
         ("tail_w", c_void_p), ("tail_b", c_float), ("tail_act", c_int32),
         ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("rowstat_out", c_void_p), ("split_seg", c_int32), ("a_dup_seg", c_int32),
+        ("tap_cols", c_int32), ("tap_mask", c_uint16 * 16),
+    ]
+
+
+class LayerNormArgs(ctypes.Structure):
+    """struct ada_layernorm_args (include/ada_hip.h)."""
+    _fields_ = [
+        ("in_", c_void_p), ("ld_in", c_int64), ("rows_out", c_int32), ("dim", c_int32), ("group_in", c_int32), ("skip", c_int32),
+        ("weight", c_void_p), ("bias", c_void_p), ("eps", c_float),
+        ("out_op", c_void_p), ("ld_op", c_int64), ("map_op", c_int32), ("map_h", c_int32), ("map_w", c_int32), ("relu", c_int32),
+        ("out_f32", c_void_p), ("ld_f32", c_int64), ("split_seg", c_int32),
+        ("weight2", c_void_p), ("bias2", c_void_p), ("out2_op", c_void_p), ("ld2_op", c_int64),
+        ("out2_group", c_int32), ("out2_skip", c_int32), ("split_seg2", c_int32), ("unshuffle_s", c_int32), ("tap_bias", c_void_p),
     ]
 
 
@@ -99,6 +112,8 @@ def load(path: Optional[str] = None):
     lib.ada_layernorm_fwd.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_float,
                                       c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p]
     lib.ada_layernorm_fwd.restype = c_int
+    lib.ada_layernorm_ex.argtypes = [ctypes.POINTER(LayerNormArgs), c_void_p]
+    lib.ada_layernorm_ex.restype = c_int
     lib.ada_patchify.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                  ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p, c_int64, c_int32, c_void_p]
     lib.ada_patchify.restype = c_int
@@ -206,7 +221,7 @@ def set_timer(t: Optional[KernelTimer]):
 def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=None, gamma=None, res=None, ldr=0,
           res_row_mod=0, res_row_off=0, flags=0, out_f32=None, ldo_f32=0, map_f32=MAP_PLAIN, out_op=None, ldo_op=0,
           map_op=MAP_PLAIN, map_h=0, map_w=0, shuffle_s=0, shuffle_c=0, tail_w=None, tail_b=0.0, tail_act=ACT_NONE, split_seg=0,
-          ln_stats=None, ln_colsum=None, rowstat_out=None, a_dup_seg=0):
+          ln_stats=None, ln_colsum=None, rowstat_out=None, a_dup_seg=0, tap_cols=0, tap_mask=None):
     op = operand_dtype()
     a = IgemmArgs()
     a.M, a.N, a.K, a.a_mode = M, N, K, a_mode
@@ -224,6 +239,10 @@ def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=Non
     a.tail_w, a.tail_b, a.tail_act = _opt(tail_w, "tail_w", torch.float32), tail_b, tail_act
     a.split_seg = split_seg
     a.a_dup_seg = a_dup_seg
+    if tap_cols:
+        a.tap_cols = tap_cols
+        for i, m in enumerate(tap_mask):
+            a.tap_mask[i] = int(m)
     a.ln_stats, a.ln_colsum = _opt(ln_stats, "ln_stats", torch.float32), _opt(ln_colsum, "ln_colsum", torch.float32)
     a.rowstat_out = _opt(rowstat_out, "rowstat_out", torch.float32)
     if _timer is not None and _timer.active:
@@ -252,12 +271,20 @@ def attention(qkv: torch.Tensor, out: torch.Tensor, batch: int, n_tokens: int, h
 
 
 def layernorm(inp, ld_in, rows_out, dim, weight, bias, eps, *, group_in=0, skip=0, out_op=None, ld_op=0, map_op=MAP_PLAIN,
-              map_h=0, map_w=0, relu=False, out_f32=None, ld_f32=0, split_seg=0):
+              map_h=0, map_w=0, relu=False, out_f32=None, ld_f32=0, split_seg=0, weight2=None, bias2=None, out2_op=None, ld2_op=0,
+              out2_group=0, out2_skip=0, split_seg2=0, unshuffle_s=0, tap_bias=None):
+    """ada_layernorm_ex (include/ada_hip.h): LayerNorm rows -> op-typed / fp32 output; optionally a second op-typed output with its own gain /
+    bias (out2_*), optionally reading a sub-pixel convolution's [coarse pixel, s*s*dim] output in fine-pixel order (unshuffle_s, tap_bias)."""
     op = operand_dtype()
-    _check(load().ada_layernorm_fwd(_dev(inp, "in", torch.float32), ld_in, rows_out, dim, group_in, skip,
-                                    _dev(weight, "weight", torch.float32), _dev(bias, "bias", torch.float32), eps,
-                                    _opt(out_op, "out_op", op), ld_op, map_op, map_h, map_w, int(relu),
-                                    _opt(out_f32, "out_f32", torch.float32), ld_f32, split_seg, _stream()), "ada_layernorm_fwd")
+    a = LayerNormArgs()
+    a.in_, a.ld_in, a.rows_out, a.dim, a.group_in, a.skip = _dev(inp, "in", torch.float32), ld_in, rows_out, dim, group_in, skip
+    a.weight, a.bias, a.eps = _dev(weight, "weight", torch.float32), _dev(bias, "bias", torch.float32), eps
+    a.out_op, a.ld_op, a.map_op, a.map_h, a.map_w, a.relu = _opt(out_op, "out_op", op), ld_op, map_op, map_h, map_w, int(relu)
+    a.out_f32, a.ld_f32, a.split_seg = _opt(out_f32, "out_f32", torch.float32), ld_f32, split_seg
+    a.weight2, a.bias2 = _opt(weight2, "weight2", torch.float32), _opt(bias2, "bias2", torch.float32)
+    a.out2_op, a.ld2_op, a.out2_group, a.out2_skip, a.split_seg2 = _opt(out2_op, "out2_op", op), ld2_op, out2_group, out2_skip, split_seg2
+    a.unshuffle_s, a.tap_bias = unshuffle_s, _opt(tap_bias, "tap_bias", torch.float32)
+    _check(load().ada_layernorm_ex(ctypes.byref(a), _stream()), "ada_layernorm_ex")
 
 
 def patchify(x, guide, batch, cg, height, width, mean, inv_std, out, ld, split=False):

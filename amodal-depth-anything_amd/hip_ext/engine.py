@@ -70,6 +70,13 @@ HEAD_ALIASES = {"tok": ("proj", "rs0", "rs1", "rs3"), "ip": tuple(f"ip{i}" for i
 # default tail wherever it applies (fused_tail_applies): 1.18 ms against 2.13 ms for the resize kernel + tail GEMM at ViT-L bs=32
 # (profiles/r03_p_fused_tail.txt).  ADA_FUSED_TAIL=0 selects the two-launch tail everywhere (A/B, and the only path for split-precision "oc2").
 FUSED_TAIL = os.environ.get("ADA_FUSED_TAIL", "1") == "1"
+# Sub-pixel merge (round 4): resize_layers[0/1] (ConvTranspose 4x4 s4 / 2x2 s2, reference DA2/dpt.py:88-100,173) and the 3x3 convolution of
+# input_projection[0/1] that follows with nothing in between (:153-159,178-179) run as ONE 3x3 convolution over the patch grid whose
+# s*s*C output columns are the output phases (functional.subpixel_merge; ada_igemm_args.tap_cols): 36 C^2 instead of 160 C^2 MACs per patch
+# at level 0, 16 C^2 instead of 40 C^2 at level 1 (39 GFLOP of 1390 per ViT-L image), one fp16 rounding of the intermediate map less, and
+# the up-sampled maps L[0] / L[1] are never written.  Exact in real arithmetic, weights composed in fp64 when they are packed.
+# ADA_SUBPIXEL=0 keeps the two launches (A/B; also the path of every split-precision level).
+SUBPIXEL = os.environ.get("ADA_SUBPIXEL", "1") == "1"
 
 
 def fused_tail_applies(half, halfp, hi, ho, split):
@@ -94,6 +101,11 @@ MAX_ROWS = (1 << 24) - 1  # row-index limit of the kernels' fast division
 
 def _r64(c: int) -> int:
     return (c + 63) // 64 * 64
+
+
+def first_is_split(split, i):
+    """Whether the 1x1 `projects[i]` feeding level i's transposed conv writes a split tensor (group "rs<i>" reads it): never merged then."""
+    return f"rs{i}" in split
 
 
 class PackedWeights:
@@ -262,6 +274,19 @@ class PackedWeights:
         self.rs0_w, self.rs0_b = convT(f32(h + "resize_layers.0.weight"), f32(h + "resize_layers.0.bias"), 4, "rs0")
         self.rs1_w, self.rs1_b = convT(f32(h + "resize_layers.1.weight"), f32(h + "resize_layers.1.bias"), 2, "rs1")
         self.rs3_w, self.rs3_b = conv3(f32(h + "resize_layers.3.weight"), "rs3"), f32(h + "resize_layers.3.bias")
+        self.sp = {}      # level -> merged sub-pixel convolution (amodal head, single-precision levels only)
+        if amodal_head and SUBPIXEL:
+            from .functional import subpixel_merge
+            for i, s_ in ((0, 4), (1, 2)):
+                if f"rs{i}" in self.split or f"ip{i}" in self.split or first_is_split(self.split, i):
+                    continue
+                wm, bias, tapb, masks = subpixel_merge(f32(f"{h}resize_layers.{i}.weight"), f32(f"{h}resize_layers.{i}.bias"),
+                                                       f32(f"{h}input_projection.{i}.0.weight"), f32(f"{h}input_projection.{i}.0.bias"), s_)
+                ci = wm.shape[2]
+                if ci % 64:
+                    wm = F.pad(wm, (0, _r64(ci) - ci))
+                self.sp[i] = dict(s=s_, w=wm.reshape(wm.shape[0], -1).to(op).contiguous(), b=bias, tapb=tapb, masks=masks,
+                                  taps_per_col=sum(bin(m).count("1") for m in masks) / float(s_ * s_))
         if amodal_head:
             self.ip_w = [conv3(f32(f"{h}input_projection.{i}.0.weight"), f"ip{i}") for i in range(4)]
             self.ip_b = [f32(f"{h}input_projection.{i}.0.bias") for i in range(4)]
@@ -350,10 +375,13 @@ class Workspace:
         oc = pw_.oc
         ocp = [_r64(c) for c in oc]
         self.ocp, self.Fp = ocp, Fp
-        self.t0 = z(P, mm("rs0") * ocp[0])
-        self.t1 = z(P, mm("rs1") * ocp[1])
+        # levels whose resize + first 3x3 conv run as one sub-pixel convolution: `projects[i]` writes a zero-bordered patch-grid tensor tp[i]
+        # (the conv's A operand); t<i> and the up-sampled map L[i] do not exist
+        self.tp = {i: z(B, ph + 2, pw + 2, ocp[i]) for i in pw_.sp}
+        self.t0 = None if 0 in pw_.sp else z(P, mm("rs0") * ocp[0])
+        self.t1 = None if 1 in pw_.sp else z(P, mm("rs1") * ocp[1])
         self.pre3 = z(B, ph + 2, pw + 2, mm("rs3") * ocp[3])
-        self.L = [z(B, g[0] + 2, g[1] + 2, mm(f"{first}{i}") * ocp[i]) for i, g in enumerate(self.grid)]
+        self.L = [None if i in pw_.sp else z(B, g[0] + 2, g[1] + 2, mm(f"{first}{i}") * ocp[i]) for i, g in enumerate(self.grid)]
         if pw_.amodal_head:
             self.ipf = [z(B * g[0] * g[1], oc[i], dtype=torch.float32) for i, g in enumerate(self.grid)]
             self.L2 = [z(B, g[0] + 2, g[1] + 2, mm(f"rn{i}") * ocp[i]) for i, g in enumerate(self.grid)]
@@ -497,11 +525,11 @@ class DepthEngine:
         raise HipExtError(f"packed weights with K={K} do not fit an operand of width {a_width} ({taps} tap(s))")
 
     @classmethod
-    def _conv3(cls, src_pad, w, M, N, grid, stride=1, cin=None, **kw):
+    def _conv3(cls, src_pad, w, M, N, grid, stride=1, cin=None, k_alg=None, **kw):
         """3x3 conv over a zero-bordered NHWC tensor (plain or split input, see _kdup)."""
         B, Hp, Wp, Cp = src_pad.shape
         kd = cls._kdup(Cp, w, taps=9)
-        k_igemm(M=M, N=N, k_alg=9 * (cin or (kd["a_dup_seg"] or Cp)), A=src_pad, W=w, a_mode=A_CONV3,
+        k_igemm(M=M, N=N, k_alg=k_alg if k_alg is not None else 9 * (cin or (kd["a_dup_seg"] or Cp)), A=src_pad, W=w, a_mode=A_CONV3,
                 conv=(grid[0], grid[1], Hp, Wp, stride), **kd, **kw)
 
     def forward(self, x: torch.Tensor, guide: Optional[torch.Tensor], normalise: Optional[bool] = None) -> torch.Tensor:
@@ -517,7 +545,7 @@ class DepthEngine:
         if not use or instrumented() or torch.cuda.is_current_stream_capturing():
             return self._forward(x, guide, norm)
         # the kernel variant / tile override / fused-tail switch in force at capture time are baked into the graph
-        key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device), debug_epoch(), FUSED_TAIL, norm)
+        key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device), debug_epoch(), FUSED_TAIL, SUBPIXEL, norm)
         with self._lock:
             g = self._graphs.get(key)
             if g is not None:
@@ -575,9 +603,13 @@ class DepthEngine:
         taps = TAPS[w.encoder]
         fold = w.fold_ln
         G = D // 64
+        ln1_done = False    # block i's norm1 output already sits in ws.y (emitted by the tap LayerNorm of block i - 1, see below)
         for i, blk in enumerate(w.blocks):
             last = i == len(w.blocks) - 1
-            if fold and i > 0:   # x arrives as the operand-typed copy written by the previous fc2 epilogue, with its row statistics
+            if ln1_done:
+                ln1_done = False
+                k_igemm(M=T, N=3 * D, K=D, A=ws.y, lda=D, W=blk["qkv_w"], bias=blk["qkv_b"], flags=EP_BIAS, out_op=ws.qkv, ldo_op=3 * D)
+            elif fold and i > 0:   # x arrives as the operand-typed copy written by the previous fc2 epilogue, with its row statistics
                 k_igemm(M=T, N=3 * D, K=D, A=ws.y, lda=D, W=blk["qkv_wf"], bias=blk["qkv_c"], ln_stats=ws.stats, ln_colsum=blk["qkv_s"],
                         flags=EP_BIAS | EP_LNFOLD, out_op=ws.qkv, ldo_op=3 * D)
             else:
@@ -614,8 +646,16 @@ class DepthEngine:
                             flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D)
             if i in taps:  # shared final LayerNorm on the tap, cls row dropped (dinov2.py:337-340)
                 tap = ws.taps[taps.index(i)]
-                k_layernorm(ws.x, D, P, D, w.norm_w, w.norm_b, LN_EPS, group_in=N, skip=1, out_op=tap, ld_op=tap.shape[1],
-                            split_seg=D if "proj" in w.split else 0)
+                if not last and not fold:
+                    # the next block's norm1 (block.py:84) reads the very rows this LayerNorm reads: one pass over x, two outputs with the
+                    # same statistics -- norm1(x) for all T rows into ws.y, norm(x) without the cls rows into the tap
+                    nb = w.blocks[i + 1]
+                    k_layernorm(ws.x, D, T, D, nb["ln1_w"], nb["ln1_b"], LN_EPS, out_op=ws.y, ld_op=D, weight2=w.norm_w, bias2=w.norm_b,
+                                out2_op=tap, ld2_op=tap.shape[1], out2_group=N, out2_skip=1, split_seg2=D if "proj" in w.split else 0)
+                    ln1_done = True
+                else:
+                    k_layernorm(ws.x, D, P, D, w.norm_w, w.norm_b, LN_EPS, group_in=N, skip=1, out_op=tap, ld_op=tap.shape[1],
+                                split_seg=D if "proj" in w.split else 0)
                 if w.readout:   # the class token of every image (row b * N of the token matrix): input row stride N * D
                     j = taps.index(i)
                     k_layernorm(ws.x, N * D, B, D, w.norm_w, w.norm_b, LN_EPS, out_op=ws.cls_op[j], ld_op=ws.cls_op[j].shape[1],
@@ -651,12 +691,16 @@ class DepthEngine:
             taps_in = ws.taps_ro
         # ---- reassemble: 1x1 project + resize (dpt.py:171-173) -> zero-bordered NHWC operand tensors -----
         KD = ws.taps[0].shape[1]
-        k_igemm(M=P, N=oc[0], k_alg=D, A=taps_in[0], W=w.proj_w[0], **self._kdup(KD, w.proj_w[0]), bias=w.proj_b[0], flags=EP_BIAS, out_op=ws.t0, ldo_op=ws.t0.shape[1], split_seg=S("rs0", ocp[0]))
-        k_igemm(M=P, N=16 * oc[0], k_alg=oc[0], A=ws.t0, W=w.rs0_w, bias=w.rs0_b, flags=EP_BIAS, **self._kdup(ws.t0.shape[1], w.rs0_w),
-                out_op=ws.L[0], ldo_op=ws.L[0].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=4, shuffle_c=oc[0], split_seg=S(first + "0", ocp[0]))
-        k_igemm(M=P, N=oc[1], k_alg=D, A=taps_in[1], W=w.proj_w[1], **self._kdup(KD, w.proj_w[1]), bias=w.proj_b[1], flags=EP_BIAS, out_op=ws.t1, ldo_op=ws.t1.shape[1], split_seg=S("rs1", ocp[1]))
-        k_igemm(M=P, N=4 * oc[1], k_alg=oc[1], A=ws.t1, W=w.rs1_w, bias=w.rs1_b, flags=EP_BIAS, **self._kdup(ws.t1.shape[1], w.rs1_w),
-                out_op=ws.L[1], ldo_op=ws.L[1].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=2, shuffle_c=oc[1], split_seg=S(first + "1", ocp[1]))
+        for i, s_ in ((0, 4), (1, 2)):
+            if i in w.sp:     # 1x1 project -> zero-bordered patch-grid tensor; the transposed conv runs inside the sub-pixel convolution below
+                k_igemm(M=P, N=oc[i], k_alg=D, A=taps_in[i], W=w.proj_w[i], **self._kdup(KD, w.proj_w[i]), bias=w.proj_b[i], flags=EP_BIAS,
+                        out_op=ws.tp[i], ldo_op=ocp[i], map_op=MAP_PAD, map_h=ph, map_w=pw)
+                continue
+            t = ws.t0 if i == 0 else ws.t1
+            rs_w, rs_b = (w.rs0_w, w.rs0_b) if i == 0 else (w.rs1_w, w.rs1_b)
+            k_igemm(M=P, N=oc[i], k_alg=D, A=taps_in[i], W=w.proj_w[i], **self._kdup(KD, w.proj_w[i]), bias=w.proj_b[i], flags=EP_BIAS, out_op=t, ldo_op=t.shape[1], split_seg=S(f"rs{i}", ocp[i]))
+            k_igemm(M=P, N=s_ * s_ * oc[i], k_alg=oc[i], A=t, W=rs_w, bias=rs_b, flags=EP_BIAS, **self._kdup(t.shape[1], rs_w),
+                    out_op=ws.L[i], ldo_op=ws.L[i].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=s_, shuffle_c=oc[i], split_seg=S(f"{first}{i}", ocp[i]))
         k_igemm(M=P, N=oc[2], k_alg=D, A=taps_in[2], W=w.proj_w[2], **self._kdup(KD, w.proj_w[2]), bias=w.proj_b[2], flags=EP_BIAS,
                 out_op=ws.L[2], ldo_op=ws.L[2].shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S(first + "2", ocp[2]))
         k_igemm(M=P, N=oc[3], k_alg=D, A=taps_in[3], W=w.proj_w[3], **self._kdup(KD, w.proj_w[3]), bias=w.proj_b[3], flags=EP_BIAS,
@@ -668,6 +712,18 @@ class DepthEngine:
         layers = ws.L
         if w.amodal_head:
             for i in range(4):
+                if i in w.sp:
+                    # resize_layers[i] + input_projection[i][0] as one sub-pixel convolution over the patch grid: [P, s*s*oc] fp32, column block
+                    # (py*s + px) = output phase; the LayerNorm reads it in fine-pixel order and takes the transposed conv's bias back out where
+                    # a tap falls into the zero padding (the outermost ring of the fine grid)
+                    sp = w.sp[i]
+                    ncol = sp["s"] * sp["s"] * oc[i]
+                    self._conv3(ws.tp[i], sp["w"], P, ncol, (ph, pw), k_alg=sp["taps_per_col"] * oc[i], bias=sp["b"], flags=EP_BIAS,
+                                out_f32=ws.ipf[i], ldo_f32=ncol, tap_cols=oc[i], tap_mask=sp["masks"])
+                    k_layernorm(ws.ipf[i], ncol, rows[i], oc[i], w.ip_ln_w[i], w.ip_ln_b[i], LN_EPS, out_op=ws.L2[i], ld_op=ws.L2[i].shape[3],
+                                map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], relu=True, split_seg=S(f"rn{i}", ocp[i]),
+                                unshuffle_s=sp["s"], tap_bias=sp["tapb"])
+                    continue
                 self._conv3(ws.L[i], w.ip_w[i], rows[i], oc[i], grid[i], cin=oc[i], bias=w.ip_b[i], flags=EP_BIAS, out_f32=ws.ipf[i], ldo_f32=oc[i])
                 k_layernorm(ws.ipf[i], oc[i], rows[i], oc[i], w.ip_ln_w[i], w.ip_ln_b[i], LN_EPS, out_op=ws.L2[i],
                             ld_op=ws.L2[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], relu=True, split_seg=S(f"rn{i}", ocp[i]))

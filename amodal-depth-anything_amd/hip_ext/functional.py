@@ -219,6 +219,48 @@ def fold_batchnorm(w, b, bn_weight, bn_bias, running_mean, running_var, eps=1e-5
     return w2, (b0 - running_mean.detach().float()) * s + bn_bias.detach().float()
 
 
+def subpixel_merge(wt, bt, w3, b3, s):
+    """Composes ``conv3x3(conv_transpose2d(x, wt, bt, stride=s), w3, b3, padding=1)`` -- nothing in between, reference
+    DA2/dpt.py:88-100,173 (resize_layers[0/1]) followed by :153-159,178-179 (input_projection[i][0]) or util/blocks.py:20-24 (layerN_rn) --
+    into ONE 3x3 convolution over the COARSE grid whose s*s*Co output columns are the s x s output phases of every coarse pixel
+    (a sub-pixel convolution).  wt [Ci, Cm, s, s], bt [Cm] or None, w3 [Co, Cm, 3, 3], b3 [Co] or None, all fp32; composed in fp64.
+
+    Fine pixel (s y + py, s x + px) reads the fine pixels (s y + py + ty - 1, s x + px + tx - 1), ty, tx in 0..2; with v = py + ty - 1, that
+    pixel belongs to coarse row y + dy, dy = floor(v / s), at inner phase v - s dy.  Hence
+
+        Wm[(py, px, co), (dy, dx), ci] = sum over (ty -> dy, tx -> dx) of  W3[co, :, ty, tx] @ Wt[ci, :, qy, qx]^T
+
+    which is non-zero for 1, 2 or 4 of the 9 coarse taps only: 36 Ci Co MACs per coarse pixel instead of 16 Ci Cm + 144 Cm Co for s = 4.
+    Returns (Wm [s*s*Co, 9, Ci], bias [s*s*Co] for interior pixels, tap_bias [s*s*Co, 9], masks [s*s]): tap_bias[n, t] is the part of the
+    bias that arrives through coarse tap t (the transposed conv's bias seen through the 3x3 filter) -- where tap t falls into the zero
+    padding the fine pixels it stands for do not exist and that part must be left out (ada_layernorm_ex tap_bias); masks[p] has bit t set
+    iff phase p touches tap t (ada_igemm_args.tap_mask)."""
+    Ci, Cm = wt.shape[:2]
+    Co = w3.shape[0]
+    dev = wt.device
+    Wm = torch.zeros(s, s, Co, 9, Ci, dtype=torch.float64, device=dev)
+    tb = torch.zeros(s, s, Co, 9, dtype=torch.float64, device=dev)
+    masks = [0] * (s * s)
+    wt64, w364 = wt.double(), w3.double()
+    bt64 = None if bt is None else bt.double()
+    for py in range(s):
+        for px in range(s):
+            for ty in range(3):
+                for tx in range(3):
+                    vy, vx = py + ty - 1, px + tx - 1
+                    dy, dx = vy // s, vx // s              # floor: -1 -> -1, s -> 1
+                    qy, qx = vy - s * dy, vx - s * dx
+                    t = (dy + 1) * 3 + (dx + 1)
+                    Wm[py, px, :, t, :] += w364[:, :, ty, tx] @ wt64[:, :, qy, qx].T
+                    if bt64 is not None:
+                        tb[py, px, :, t] += w364[:, :, ty, tx] @ bt64
+                    masks[py * s + px] |= 1 << t
+    bias = tb.sum(-1)
+    if b3 is not None:
+        bias = bias + b3.double().view(1, 1, Co)
+    return (Wm.reshape(s * s * Co, 9, Ci).float(), bias.reshape(-1).float().contiguous(), tb.reshape(s * s * Co, 9).float().contiguous(), masks)
+
+
 def residual_conv_unit(x, w1, b1, w2, b2):
     """ResidualConvUnit (reference blocks.py:57-80) with ReLU / residual fused into the conv epilogues."""
     _need_cuda(x, "residual_conv_unit input")

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADA_ABI_VERSION 4
+#define ADA_ABI_VERSION 5
 
 /* status codes */
 #define ADA_OK 0
@@ -137,6 +137,14 @@ typedef struct ada_igemm_args {
                                3x3 conv) and the contraction runs over THREE segments (hi, lo, hi -- the third re-reads the first) against
                                weights packed [w_hi | w_hi | w_lo]: x_hi w_hi + x_lo w_hi + x_hi w_lo.  K = 3 * a_dup_seg (x 9 for CONV3),
                                lda >= 2 * a_dup_seg.  0 = plain operand */
+    int32_t tap_cols;       /* CONV3, > 0: sub-pixel convolution.  A stride-s transposed convolution (DA2/dpt.py:88-100 resize_layers[0/1]) followed,
+                               with nothing in between, by a 3x3 convolution (DA2/dpt.py:153-159 input_projection[i][0]) is ONE 3x3 convolution
+                               over the COARSE grid with s*s*Cout output columns: column block p = py*s + px (tap_cols = Cout columns each) is
+                               output phase (py, px) and touches only the coarse taps its 3x3 fine window reaches -- 1, 2 or 4 of the 9.  The
+                               weights are composed by the caller ([N, 9*lda] tap-major as for any CONV3, zero in the untouched blocks) and
+                               tap_mask[p] (bit 3*(dy+1) + (dx+1)) names the touched taps; the kernel's k-loop for an N-tile walks the union of
+                               its blocks' taps only: 36 C^2 MACs per coarse pixel instead of 160 C^2 for s = 4.  N / tap_cols <= 16.  0 = off */
+    uint16_t tap_mask[16];
 } ada_igemm_args;
 
 int ada_igemm(const ada_igemm_args* args, void* stream);
@@ -176,6 +184,40 @@ int ada_layernorm_fwd(const float* in, int64_t ld_in, int32_t rows_out, int32_t 
                       void* out_op, int64_t ld_op, int32_t map_op, int32_t map_h, int32_t map_w,
                       int32_t relu,
                       float* out_f32, int64_t ld_f32, int32_t split_seg, void* stream);
+
+/* The same kernel with its two extensions (struct arguments; zero-initialise what is not used):
+ *  - a SECOND operand-typed output of the same rows with the same statistics but its own gain / bias: the four tap LayerNorms of
+ *    get_intermediate_layers (DA2/dinov2.py:337-340: shared final norm, cls token dropped) read the very rows the next block's norm1
+ *    (block.py:84) reads, so one pass emits both -- rows are taken in groups of out2_group, the first out2_skip rows of a group are
+ *    left out of the second output and the others compacted;
+ *  - sub-pixel input (unshuffle_s = s > 0): `in` is the [coarse pixel, s*s*dim] fp32 output of a sub-pixel convolution
+ *    (ada_igemm_args.tap_cols) and output row r is FINE pixel (b, Y, X) of the map_h x map_w grid, whose values are columns
+ *    [(Y%s * s + X%s) * dim, +dim) of coarse pixel (b, Y/s, X/s) -- the channels-first LayerNorm + ReLU of input_projection
+ *    (DA2/dpt.py:153-159) reads the merged convolution's output in place.  tap_bias [s*s*dim, 9] (optional) holds, per output column
+ *    and coarse tap, the transposed convolution's bias as seen through the 3x3 filter; on the outermost ring of the fine grid the taps
+ *    that fall outside the image are subtracted (zero padding applies to the transposed conv's OUTPUT, bias included). */
+typedef struct ada_layernorm_args {
+    const float* in;
+    int64_t ld_in;
+    int32_t rows_out, dim, group_in, skip;
+    const float* weight;
+    const float* bias;
+    float eps;
+    void* out_op;
+    int64_t ld_op;
+    int32_t map_op, map_h, map_w, relu;
+    float* out_f32;
+    int64_t ld_f32;
+    int32_t split_seg;
+    const float* weight2;
+    const float* bias2;
+    void* out2_op;
+    int64_t ld2_op;
+    int32_t out2_group, out2_skip, split_seg2;
+    int32_t unshuffle_s;
+    const float* tap_bias;
+} ada_layernorm_args;
+int ada_layernorm_ex(const ada_layernorm_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Patchify: the im2col half of the 14x14/stride-14 patch-embed convolutions

@@ -57,6 +57,22 @@ def test_igemm_args_struct_layout_matches_c(tmp_path):
         assert getattr(hip_ext.IgemmArgs, f).offset == off, f
 
 
+def test_layernorm_args_struct_layout_matches_c(tmp_path):
+    names = [f[0] for f in hip_ext.LayerNormArgs._fields_]
+    cnames = ["in" if f == "in_" else f for f in names]
+    prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){", 'printf("%zu\\n", sizeof(ada_layernorm_args));']
+    prog += [f'printf("%zu\\n", offsetof(ada_layernorm_args, {f}));' for f in cnames]
+    prog += ["return 0;}"]
+    c = tmp_path / "layout_ln.c"
+    c.write_text("\n".join(prog))
+    exe = tmp_path / "layout_ln"
+    subprocess.check_call(["gcc", "-std=c99", "-o", str(exe), str(c)])
+    vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert vals[0] == ctypes.sizeof(hip_ext.LayerNormArgs)
+    for f, off in zip(names, vals[1:]):
+        assert getattr(hip_ext.LayerNormArgs, f).offset == off, f
+
+
 def test_constants_match_header():
     src = open(HEADER).read()
     consts = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(ADA_[A-Z0-9_]+)\s+\(?(-?(?:0x)?[0-9A-Fa-f]+)\)?\s", src)}

@@ -24,6 +24,9 @@ def test_bench_gpus2_launches_its_own_ranks():
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
     assert line["config"]["global_batch"] == 8 and line["scaling"] == "weak"
     assert line["data"].startswith("stub") and line["value"] > 0
+    # per-rank times of the headline block: the value is computed from the slowest rank, the spread shows a straggler
+    assert len(line["ms_per_step_ranks"]) == 2 and abs(max(line["ms_per_step_ranks"]) - line["ms_per_step"]) < 1e-6
+    assert 0.0 <= line["rank_spread_pct"] < 100.0 and line["cpu_baseline"] is None and "N = 1" in line["cpu_baseline_note"]
     assert len(r.stdout.strip().splitlines()) == 1, "only rank 0's JSON line may reach stdout"
 
 

@@ -154,6 +154,78 @@ def test_igemm_conv_transpose_shuffle(hip, s, C, Ci):
     _close(out[:, 1:-1, 1:-1], ref, 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="convT")
 
 
+# Sub-pixel convolution: ConvTranspose2d(k = s, stride s) followed by Conv2d(3x3, padding 1) with nothing in between (reference DA2/dpt.py
+# resize_layers[0/1] -> input_projection[i][0]) as ONE masked-tap 3x3 convolution over the coarse grid + the LayerNorm that reads it
+@pytest.mark.parametrize("s,Ci,Cm,Co,H,W,cfg", [(4, 48, 48, 48, 7, 5, -1), (2, 96, 96, 96, 9, 6, -1), (4, 256, 256, 256, 12, 11, 3), (2, 512, 128, 512, 10, 13, 3),
+                                               (4, 64, 64, 64, 1, 1, -1), (2, 64, 64, 192, 1, 3, 4), (4, 96, 64, 96, 20, 17, 3), (4, 128, 128, 128, 16, 16, 1)])
+def test_subpixel_conv_matches_conv_of_conv_transpose(hip, forced_tile, s, Ci, Cm, Co, H, W, cfg):
+    from hip_ext.functional import subpixel_merge
+    op = _op(hip)
+    B = 2
+    cp = (Ci + 63) // 64 * 64
+    x = _rand(B, Ci, H, W, seed=31).to(op).float()
+    wt = _rand(Ci, Cm, s, s, seed=32) * Ci ** -0.5
+    bt = _rand(Cm, seed=33)
+    w3 = _rand(Co, Cm, 3, 3, seed=34) * (9 * Cm) ** -0.5
+    b3 = _rand(Co, seed=35)
+    ref = F.conv2d(F.conv_transpose2d(x, wt, bt, stride=s), w3, b3, padding=1)          # fp32, [B, Co, sH, sW]
+    wm, bias, tapb, masks = subpixel_merge(wt, bt, w3, b3, s)
+    assert sum(bin(m).count("1") for m in masks) == (36 if s == 4 else 16)
+    wp = torch.zeros(s * s * Co, 9, cp)
+    wp[..., :Ci] = wm
+    N = s * s * Co
+    P = B * H * W
+    out = torch.full((P, N), float("nan"), device=DEV)
+    if cfg >= 0:
+        forced_tile(cfg, 0)
+    hip.igemm(M=P, N=N, K=9 * cp, A=_pad_nhwc(x, cp, op).to(DEV), lda=cp, W=wp.reshape(N, 9 * cp).to(op).to(DEV), a_mode=hip.A_CONV3,
+              conv=(H, W, H + 2, W + 2, 1), bias=bias.to(DEV), flags=hip.EP_BIAS, out_f32=out, ldo_f32=N, tap_cols=Co, tap_mask=masks)
+    if cfg >= 0:
+        _check_tile(hip, cfg, 0)
+    # (a) the raw [coarse pixel, phase * Co] output, un-shuffled on the host, with the ring correction applied on the host
+    got = out.cpu().view(B, H, W, s, s, Co).permute(0, 5, 1, 3, 2, 4).reshape(B, Co, s * H, s * W).clone()
+    tb = tapb.view(s, s, Co, 3, 3)
+    Y, X = torch.arange(s * H), torch.arange(s * W)
+    for dy in range(3):
+        for dx in range(3):
+            miss_y = (Y // s + dy - 1 < 0) | (Y // s + dy - 1 >= H)
+            miss_x = (X // s + dx - 1 < 0) | (X // s + dx - 1 >= W)
+            miss = (miss_y[:, None] | miss_x[None, :]).float()                            # [sH, sW]
+            t = tb[Y % s][:, X % s][:, :, :, dy, dx].permute(2, 0, 1)                     # [Co, sH, sW]
+            got -= (miss[None] * t)[None]
+    _close(got, ref, 2e-3, rtol=3e-3, what="sub-pixel conv (host un-shuffle)")
+    # (b) the LayerNorm that consumes it in place: channels-first LN + ReLU into a zero-bordered operand tensor (DA2/dpt.py:153-159)
+    g, beta = 1.0 + 0.1 * _rand(Co, seed=36), 0.1 * _rand(Co, seed=37)
+    outp = torch.zeros(B, s * H + 2, s * W + 2, Co, dtype=op, device=DEV)
+    hip.layernorm(out, N, B * s * H * s * W, Co, g.to(DEV), beta.to(DEV), 1e-6, out_op=outp, ld_op=Co, map_op=hip.MAP_PAD, map_h=s * H, map_w=s * W,
+                  relu=True, unshuffle_s=s, tap_bias=tapb.to(DEV))
+    ln_ref = F.relu(F.layer_norm(ref.permute(0, 2, 3, 1), (Co,), g, beta, 1e-6))
+    _close(outp[:, 1:-1, 1:-1], ln_ref, 6e-3, rtol=1e-2 if op == torch.bfloat16 else 4e-3, what="LayerNorm over the sub-pixel output")
+    border = outp.clone()
+    border[:, 1:-1, 1:-1] = 0
+    assert float(border.abs().max()) == 0.0
+
+
+def test_layernorm_second_output_drops_cls_rows(hip):
+    """One pass, two normalised outputs of the same rows: all rows with (gain, bias) 1 -> the next block's LN1; the rows of every group of N
+    but the first with (gain, bias) 2, compacted -> the tap LayerNorm (DA2/dinov2.py:337-340)."""
+    op = _op(hip)
+    B, N, D = 3, 11, 384
+    x = _rand(B * N, D, seed=41) * 2 + 0.3
+    g1, b1, g2, b2 = 1 + 0.1 * _rand(D, seed=42), 0.1 * _rand(D, seed=43), 1 + 0.1 * _rand(D, seed=44), 0.1 * _rand(D, seed=45)
+    o1 = torch.zeros(B * N, D, dtype=op, device=DEV)
+    o2 = torch.zeros(B * (N - 1), 2 * D, dtype=op, device=DEV)
+    hip.layernorm(x.to(DEV), D, B * N, D, g1.to(DEV), b1.to(DEV), 1e-6, out_op=o1, ld_op=D, weight2=g2.to(DEV), bias2=b2.to(DEV), out2_op=o2, ld2_op=2 * D,
+                  out2_group=N, out2_skip=1, split_seg2=D)
+    r1 = F.layer_norm(x, (D,), g1, b1, 1e-6)
+    r2 = F.layer_norm(x.view(B, N, D)[:, 1:].reshape(-1, D), (D,), g2, b2, 1e-6)
+    tol = dict(atol=2e-2, rtol=1e-2) if op == torch.bfloat16 else dict(atol=2e-3, rtol=2e-3)
+    _close(o1, r1, tol["atol"], rtol=tol["rtol"], what="LN main output")
+    hi, lo = o2[:, :D].float().cpu(), o2[:, D:].float().cpu()
+    _close(hi, r2, tol["atol"], rtol=tol["rtol"], what="LN second output (hi)")
+    _close(hi + lo, r2, 2e-5 if op == torch.float16 else 2e-4, rtol=2e-5 if op == torch.float16 else 2e-4, what="LN second output (hi + lo)")
+
+
 @pytest.mark.parametrize("act", ["sigmoid", "relu", "none"])
 def test_igemm_tail(hip, act):
     op = _op(hip)

@@ -47,6 +47,21 @@ ADA_DEV void half_exchange(float x, float& lo, float& hi_) {
     hi_ = __builtin_bit_cast(float, b);
 }
 
+// Maxima as the instruction, not as fmaxf(): in IEEE mode the compiler may not assume that an operand is no signalling NaN and canonicalises
+// it first ("v_max_f32 x, x, x"), which -- depending on how the expression tree is shaped -- put 12 extra VALU instructions into every 64-key
+// tile of the mixed-stream kernel (20 for the 16 scores of a key block instead of 8: profiles/r04_d_attention_isa_census.txt).  Scores come out
+// of MFMAs on finite operands; -inf (masked keys) is handled by v_max like any number.
+ADA_DEV float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+ADA_DEV float vmax2(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // Row sum of P: two fp32 adds of the unrounded exponentials per pair.  (v_dot2c_f32_f16 on the packed pair and v_pk_add_f16 into a packed
 // accumulator were A/B-ed in round 2 -- tools/ubench/softmax_slot.hip, profiles/r02_a_softmax_slot_ubench.txt -- no difference in the kernel.)
 struct RowSum {
@@ -353,15 +368,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_mix(const op_t* __res
     const unsigned v_voff = (unsigned)srow * row_bytes + (unsigned)((sc ^ (((srow >> 1) & 1) << 2)) * 16);
     const unsigned pass_bytes = 32u * row_bytes;
     char* const my_lds = smem + wave * 1024;
+    // the tile offset rides in the instruction's SCALAR offset (it takes part in the bounds check like the vector offset: keys >= n_tok
+    // still read as zero) -- as a VALU add to the lane offset it cost four instructions per tile and wave
     auto stage_k = [&](int buf, int tile) {
-        const unsigned so = (unsigned)tile * 2u * pass_bytes;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(my_lds + buf * K_TILE), 16, (int)(k_voff + so), 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(my_lds + buf * K_TILE + 4096), 16, (int)(k_voff + so + pass_bytes), 0, 0, 0);
+        const int so = __builtin_amdgcn_readfirstlane((int)((unsigned)tile * 2u * pass_bytes));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(my_lds + buf * K_TILE), 16, (int)k_voff, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(my_lds + buf * K_TILE + 4096), 16, (int)(k_voff + pass_bytes), so, 0, 0);
     };
     auto stage_v = [&](int buf, int tile) {
-        const unsigned so = (unsigned)tile * 2u * pass_bytes;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(my_lds + 2 * K_TILE + buf * V_TILE), 16, (int)(v_voff + so), 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(my_lds + 2 * K_TILE + buf * V_TILE + 4096), 16, (int)(v_voff + so + pass_bytes), 0, 0, 0);
+        const int so = __builtin_amdgcn_readfirstlane((int)((unsigned)tile * 2u * pass_bytes));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(my_lds + 2 * K_TILE + buf * V_TILE), 16, (int)v_voff, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(my_lds + 2 * K_TILE + buf * V_TILE + 4096), 16, (int)(v_voff + pass_bytes), so, 0, 0);
     };
 
     f32x16 o[2], negm, sT[2];
@@ -481,29 +498,34 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_mix(const op_t* __res
         if (wave_active) {
             // ---- A: row max, decision -----------------------------------------------------------
             if (j == nt - 1) {
+                asm volatile(";;ADA_RARE_BEGIN last tile: keys >= n_tok masked");   // markers for tools/attn_isa_table.py: not on the steady-state path
                 const int kv0 = j * KVB;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         if (kv0 + kb * 32 + crow32(r, hi) >= n_tok) sT[kb][r] = -INFINITY;
+                asm volatile(";;ADA_RARE_END");
             }
             // the maximum over key block 0 (mx0) was taken under the last four MFMAs of the previous iteration
             if (j == nt - 1 || j == 0) {
-                mx0 = __builtin_fmaxf(sT[0][0], sT[0][1]);
+                asm volatile(";;ADA_RARE_BEGIN first / last tile: maximum of key block 0 not taken under the previous tile's MFMAs");
+                mx0 = vmax2(sT[0][0], sT[0][1]);
 #pragma unroll
-                for (int r = 2; r < 16; r += 2) mx0 = __builtin_fmaxf(__builtin_fmaxf(mx0, sT[0][r]), sT[0][r + 1]);
+                for (int r = 2; r < 16; r += 2) mx0 = vmax3(mx0, sT[0][r], sT[0][r + 1]);
+                asm volatile(";;ADA_RARE_END");
             }
-            float mx1 = __builtin_fmaxf(sT[1][0], sT[1][1]);
+            float mx1 = vmax3(mx0, sT[1][0], sT[1][1]);     // key block 1 joins the running maximum of key block 0: 8 v_max3 for 16 + 1 values
 #pragma unroll
-            for (int r = 2; r < 16; r += 2) mx1 = __builtin_fmaxf(__builtin_fmaxf(mx1, sT[1][r]), sT[1][r + 1]);
-            float mx = __builtin_fmaxf(mx0, mx1);
+            for (int r = 2; r < 16; r += 2) mx1 = vmax3(mx1, sT[1][r], sT[1][r + 1]);
+            float mx = mx1;
             {
                 float a, b2;
                 half_exchange(mx, a, b2);
-                mx = __builtin_fmaxf(a, b2);
+                mx = vmax2(a, b2);
             }
             if (j == 0 || __any(mx > RESCALE_THR)) {
+                asm volatile(";;ADA_RARE_BEGIN deferred rescale (first tile, or a row maximum grew by more than 2^8)");
                 const bool mv = (j == 0) || (mx > RESCALE_THR);
                 const float m_new = mv ? m_run + mx : m_run;
                 const float delta = m_new - m_run;
@@ -532,6 +554,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_mix(const op_t* __res
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sT[kb][r] -= delta;
+                asm volatile(";;ADA_RARE_END");
             }
             rs = RowSum();
             fence();
@@ -560,8 +583,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_mix(const op_t* __res
                     read_v(PB{}, g >> 1, g & 1, 1);
                 } else {   // key block 0 of S(j+1) is complete: start on its row maximum
                     const int r = (g - 4) * 4;
-                    const float t = __builtin_fmaxf(__builtin_fmaxf(sT[0][r], sT[0][r + 1]), __builtin_fmaxf(sT[0][r + 2], sT[0][r + 3]));
-                    mx0 = g == 4 ? t : __builtin_fmaxf(mx0, t);
+                    mx0 = g == 4 ? vmax2(sT[0][0], sT[0][1]) : vmax3(mx0, sT[0][r], sT[0][r + 1]);
+                    mx0 = vmax3(mx0, sT[0][r + 2], sT[0][r + 3]);
                 }
                 fence();
             }

@@ -85,6 +85,7 @@ struct IgemmDev {
     int rowstat_groups;       // N / 64
     int split_seg;   // > 0: the op-typed output is written as [hi | lo] in two column segments of this width (split precision)
     int a_dup_seg;   // > 0: the A operand is a [hi | lo] split tensor contracted as (hi, lo, hi) against [w_hi | w_hi | w_lo] weights
+    int a_wrap;      // PLAIN, > 0: the A row is a_wrap elements long and the k-walk wraps around once: K = 2 * a_wrap against [w_hi | w_lo] weights
     int tap_cols;    // CONV3, > 0: the N columns come in blocks of tap_cols ("phases" of a sub-pixel convolution) that use only some of the 9 taps
     unsigned long long tap_bits[3];   // 9-bit tap masks of up to 16 blocks, seven per word
     FastDiv dShC, dShS;
@@ -337,10 +338,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     // k-step kt -> element offsets of its A and W slabs (wave-uniform scalars)
     // a split A operand ([hi | lo] per row / per tap) is contracted as three k segments (hi, lo, hi): segment 2 re-reads segment 0
     const int sps = p.a_dup_seg / BK;                                   // k-steps per segment (0: plain operand)
+    const int wrap = sps > 0 ? 2 * sps : p.a_wrap / BK;                 // PLAIN: k-step at which the A walk starts over (0: never)
     const int cps = sps > 0 ? 3 * sps : (int)(p.lda / BK);              // k-steps per conv tap
     auto slab_offsets = [&](int kt, long& aoff, long& boff) {
         if (p.a_mode == ADA_A_PLAIN) {
-            aoff = (long)((sps > 0 && kt >= 2 * sps) ? kt - 2 * sps : kt) * BK;
+            aoff = (long)((wrap > 0 && kt >= wrap) ? kt - wrap : kt) * BK;
         } else {
             const int tap = kt / cps;
             int kc = kt - tap * cps;
@@ -1044,7 +1046,7 @@ static inline double tile_time(long M, long N, int bm, int bn, int occ, double e
 // main loop of the 256x256 tile: variant 16 forces the hand-scheduled 4-wave loop, 4 the single-barrier 8-wave loop; 0 (default) picks the
 // 4-wave loop where its main loop outweighs its slower prologue / epilogue (measured: k-loops of >= 128 k-tiles)
 // (its scalar A-offset counters assume a monotonic walk: a split operand, whose third k segment re-reads the first, stays on the 8-wave loop)
-static inline bool use_pipe4(const IgemmDev& d) { return d.a_dup_seg == 0 && d.tap_cols == 0 && (d.variant >= 16 || (d.variant == 0 && d.K >= 8192)); }
+static inline bool use_pipe4(const IgemmDev& d) { return d.a_dup_seg == 0 && d.a_wrap == 0 && d.tap_cols == 0 && (d.variant >= 16 || (d.variant == 0 && d.K >= 8192)); }
 
 template <int EPI>
 int launch_epi(IgemmDev& d, hipStream_t s, int force) {
@@ -1140,7 +1142,7 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
         ADA_REQUIRE(a->M % (a->Ho * a->Wo) == 0, ADA_EINVAL, "ada_igemm: M must be batch*Ho*Wo");
     } else {
         ADA_REQUIRE(a->a_mode == ADA_A_PLAIN, ADA_EINVAL, "ada_igemm: unknown a_mode %d", a->a_mode);
-        ADA_REQUIRE(a->a_dup_seg > 0 || a->lda >= a->K, ADA_EINVAL, "ada_igemm: lda=%ld < K=%d", (long)a->lda, a->K);
+        ADA_REQUIRE(a->a_dup_seg > 0 || a->a_wrap > 0 || a->lda >= a->K, ADA_EINVAL, "ada_igemm: lda=%ld < K=%d", (long)a->lda, a->K);
     }
     const int f = a->flags;
     ADA_REQUIRE(!(f & ADA_EP_BIAS) || a->bias, ADA_EINVAL, "ada_igemm: EP_BIAS without bias");
@@ -1192,6 +1194,10 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
         const int cols = shuffle ? a->shuffle_c : a->N;
         ADA_REQUIRE(cols <= a->split_seg && a->ldo_op >= 2L * a->split_seg, ADA_EINVAL, "ada_igemm: split_seg=%d too small for %d columns / ldo_op=%ld", a->split_seg, cols, (long)a->ldo_op);
     }
+    if (a->a_wrap != 0) {
+        ADA_REQUIRE(a->a_mode == ADA_A_PLAIN && a->a_dup_seg == 0 && a->a_wrap > 0 && a->a_wrap % 64 == 0 && a->K == 2 * a->a_wrap && a->lda >= a->a_wrap, ADA_EINVAL,
+                    "ada_igemm: a_wrap=%d needs a plain operand, K == 2 * a_wrap (K=%d) and lda >= a_wrap", a->a_wrap, a->K);
+    }
     if (a->tap_cols != 0) {
         ADA_REQUIRE(a->a_mode == ADA_A_CONV3 && a->tap_cols > 0 && a->N % a->tap_cols == 0 && a->N / a->tap_cols <= 16, ADA_EINVAL,
                     "ada_igemm: tap_cols=%d needs a CONV3 operand and N = (1..16) * tap_cols (N=%d)", a->tap_cols, a->N);
@@ -1223,6 +1229,7 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.shuffle_s = a->shuffle_s; d.shuffle_c = a->shuffle_c;
     d.split_seg = a->split_seg;
     d.a_dup_seg = a->a_dup_seg;
+    d.a_wrap = a->a_wrap;
     d.tap_cols = a->tap_cols;
     d.tap_bits[0] = d.tap_bits[1] = d.tap_bits[2] = 0;
     if (a->tap_cols > 0)

@@ -113,7 +113,7 @@ class PackedWeights:
     with the *raw* model's key names (``pretrained.*``, ``depth_head.*``)."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], encoder: str, guided: bool, amodal_head: bool, split_head=False,
-                 fold_ln: bool = False):
+                 fold_ln: bool = False, enc_split_blocks: int = 0):
         op = operand_dtype()
         cfg = VIT[encoder]
         D = cfg["dim"]
@@ -136,6 +136,13 @@ class PackedWeights:
         # epilogue that writes the residual stream (ADA_EP_ROWSTATS): no stand-alone LayerNorm launch between the GEMMs of a block
         # (only the very first LayerNorm of the encoder, whose input comes from the patch embedding, runs as a kernel).  MLP blocks only.
         self.fold_ln = bool(fold_ln) and cfg["ffn"] == "mlp"
+        # enc_split_blocks = K: the linear layers of the FIRST K transformer blocks run in split precision.  Operand rounding noise injected
+        # early is amplified by every later block (oracle study, profiles/r04_e_raw_vitg_operand_noise_by_block.txt: blocks 0-9 of ViT-G carry
+        # half of the encoder's share, blocks 30-39 a fiftieth), so for the unbounded-output ViT-G model, whose encoder alone reaches
+        # 0.7e-3 ... 1.05e-3 depending on the weight draw, the head's split precision is not enough.  qkv and fc1 / w12 read the LayerNorm
+        # output as [hi | lo] (full three-term product); proj and fc2 / w3 read activations that exist in the operand type only (attention
+        # output, MLP hidden) against [w_hi | w_lo] weights (ada_igemm_args.a_wrap: the weight's rounding error goes, the activation's stays).
+        self.enc_split_blocks = 0 if self.fold_ln else max(0, min(int(enc_split_blocks), cfg["depth"]))
         self.dim, self.depth, self.heads, self.ffn = D, cfg["depth"], cfg["heads"], cfg["ffn"]
 
         def f32(name):
@@ -194,15 +201,28 @@ class PackedWeights:
             # kernel runs its softmax in base 2 (exp2 is the native transcendental), softmax_e(s) == softmax_2(s * log2 e)
             qw[:D] *= Q_PRESCALE
             qb[:D] *= Q_PRESCALE
+            esplit = i < self.enc_split_blocks
+
+            def lin3(wm):   # [N, K] -> [w_hi | w_hi | w_lo] (against a [hi | lo] activation, a_dup_seg) for the split blocks
+                if not esplit:
+                    return lin(wm)
+                hi_ = wm.to(op)
+                return torch.cat([hi_, hi_, (wm - hi_.float()).to(op)], dim=1).contiguous()
+
+            def lin2(wm):   # [N, K] -> [w_hi | w_lo] (against a plain activation walked twice, a_wrap)
+                if not esplit:
+                    return lin(wm)
+                hi_ = wm.to(op)
+                return torch.cat([hi_, (wm - hi_.float()).to(op)], dim=1).contiguous()
             blk = dict(
-                ln1_w=f32(b + "norm1.weight"), ln1_b=f32(b + "norm1.bias"),
-                qkv_w=lin(qw), qkv_b=qb,
-                proj_w=lin(f32(b + "attn.proj.weight")), proj_b=f32(b + "attn.proj.bias"), ls1=f32(b + "ls1.gamma"),
+                ln1_w=f32(b + "norm1.weight"), ln1_b=f32(b + "norm1.bias"), esplit=esplit,
+                qkv_w=lin3(qw), qkv_b=qb,
+                proj_w=lin2(f32(b + "attn.proj.weight")), proj_b=f32(b + "attn.proj.bias"), ls1=f32(b + "ls1.gamma"),
                 ln2_w=f32(b + "norm2.weight"), ln2_b=f32(b + "norm2.bias"), ls2=f32(b + "ls2.gamma"),
             )
             if self.ffn == "mlp":
-                blk.update(fc1_w=lin(f32(b + "mlp.fc1.weight")), fc1_b=f32(b + "mlp.fc1.bias"),
-                           fc2_w=lin(f32(b + "mlp.fc2.weight")), fc2_b=f32(b + "mlp.fc2.bias"))
+                blk.update(fc1_w=lin3(f32(b + "mlp.fc1.weight")), fc1_b=f32(b + "mlp.fc1.bias"),
+                           fc2_w=lin2(f32(b + "mlp.fc2.weight")), fc2_b=f32(b + "mlp.fc2.bias"))
                 blk["hidden"] = blk["fc1_w"].shape[0]
                 if self.fold_ln:
                     def fold(wmat, bias, g, beta):   # LN(x) W^T + b = rstd (x W'^T - mean s) + c
@@ -219,8 +239,8 @@ class PackedWeights:
                 # interleave x1 / x2 rows in groups of 32 so one wave's two MFMA column tiles hold the gate pair
                 idx = torch.arange(hid, device=w12.device).reshape(-1, 32)
                 order = torch.stack([idx, idx + hid], dim=1).reshape(-1)
-                blk.update(w12_w=lin(w12[order]), w12_b=b12[order].contiguous(),
-                           w3_w=lin(f32(b + "mlp.w3.weight")), w3_b=f32(b + "mlp.w3.bias"))
+                blk.update(w12_w=lin3(w12[order]), w12_b=b12[order].contiguous(),
+                           w3_w=lin2(f32(b + "mlp.w3.weight")), w3_b=f32(b + "mlp.w3.bias"))
                 blk["hidden"] = hid
             self.blocks.append(blk)
         self.norm_w, self.norm_b = f32(p + "norm.weight"), f32(p + "norm.bias")
@@ -357,7 +377,9 @@ class Workspace:
 
         self.a_pe = z(P, 2 * pw_.pe_seg)     # split-precision patches: [hi | lo]
         self.x = z(T, D, dtype=torch.float32)
-        self.y = z(T, D)     # LayerNorm output; with folded LayerNorms: the operand-typed copy of the residual stream itself
+        # LayerNorm output ([hi | lo] column segments for the split-precision blocks: PackedWeights.enc_split_blocks); with folded LayerNorms: the
+        # operand-typed copy of the residual stream itself
+        self.y = z(T, 2 * D if pw_.enc_split_blocks > 0 else D)
         if pw_.fold_ln:
             self.part = z(T, D // 64, 2, dtype=torch.float32)    # per-row partial (sum, sum of squares), one slot per 64 columns
             self.stats = z(T, 2, dtype=torch.float32)            # (mean, rstd) per row
@@ -603,18 +625,28 @@ class DepthEngine:
         taps = TAPS[w.encoder]
         fold = w.fold_ln
         G = D // 64
+        ldy = ws.y.shape[1]
+
+        def a_ln(blk_, wname):      # A-operand arguments of a linear layer that reads the LayerNorm output ws.y: plain, or [hi | lo] in a split block
+            return dict(K=3 * D, lda=ldy, a_dup_seg=D) if blk_["esplit"] else dict(K=D, lda=ldy)
+
+        def a_act(blk_, kin):       # ... that reads an operand-typed activation of width kin: plain, or walked twice against [w_hi | w_lo]
+            return dict(K=2 * kin, lda=kin, a_wrap=kin) if blk_["esplit"] else dict(K=kin, lda=kin)
+
+        def seg(blk_):              # split_seg of the LayerNorm that feeds blk_'s linear layers
+            return D if blk_["esplit"] else 0
         ln1_done = False    # block i's norm1 output already sits in ws.y (emitted by the tap LayerNorm of block i - 1, see below)
         for i, blk in enumerate(w.blocks):
             last = i == len(w.blocks) - 1
             if ln1_done:
                 ln1_done = False
-                k_igemm(M=T, N=3 * D, K=D, A=ws.y, lda=D, W=blk["qkv_w"], bias=blk["qkv_b"], flags=EP_BIAS, out_op=ws.qkv, ldo_op=3 * D)
+                k_igemm(M=T, N=3 * D, k_alg=D, A=ws.y, W=blk["qkv_w"], bias=blk["qkv_b"], flags=EP_BIAS, out_op=ws.qkv, ldo_op=3 * D, **a_ln(blk, "qkv_w"))
             elif fold and i > 0:   # x arrives as the operand-typed copy written by the previous fc2 epilogue, with its row statistics
                 k_igemm(M=T, N=3 * D, K=D, A=ws.y, lda=D, W=blk["qkv_wf"], bias=blk["qkv_c"], ln_stats=ws.stats, ln_colsum=blk["qkv_s"],
                         flags=EP_BIAS | EP_LNFOLD, out_op=ws.qkv, ldo_op=3 * D)
             else:
-                k_layernorm(ws.x, D, T, D, blk["ln1_w"], blk["ln1_b"], LN_EPS, out_op=ws.y, ld_op=D)
-                k_igemm(M=T, N=3 * D, K=D, A=ws.y, lda=D, W=blk["qkv_w"], bias=blk["qkv_b"], flags=EP_BIAS, out_op=ws.qkv, ldo_op=3 * D)
+                k_layernorm(ws.x, D, T, D, blk["ln1_w"], blk["ln1_b"], LN_EPS, out_op=ws.y, ld_op=ldy, split_seg=seg(blk))
+                k_igemm(M=T, N=3 * D, k_alg=D, A=ws.y, W=blk["qkv_w"], bias=blk["qkv_b"], flags=EP_BIAS, out_op=ws.qkv, ldo_op=3 * D, **a_ln(blk, "qkv_w"))
             k_attention(ws.qkv, ws.o, B, N, heads)
             hid = blk["hidden"]
             if fold:
@@ -631,26 +663,26 @@ class DepthEngine:
                             flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL | EP_ROWSTATS, out_f32=ws.x, ldo_f32=D, out_op=ws.y, ldo_op=D, rowstat_out=ws.part)
                     k_rowstats_finalize(ws.part, T, G, LN_EPS, ws.stats)
             else:
-                k_igemm(M=T, N=D, K=D, A=ws.o, lda=D, W=blk["proj_w"], bias=blk["proj_b"], gamma=blk["ls1"], res=ws.x, ldr=D,
-                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D)
-                k_layernorm(ws.x, D, T, D, blk["ln2_w"], blk["ln2_b"], LN_EPS, out_op=ws.y, ld_op=D)
+                k_igemm(M=T, N=D, k_alg=D, A=ws.o, W=blk["proj_w"], bias=blk["proj_b"], gamma=blk["ls1"], res=ws.x, ldr=D,
+                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, D))
+                k_layernorm(ws.x, D, T, D, blk["ln2_w"], blk["ln2_b"], LN_EPS, out_op=ws.y, ld_op=ldy, split_seg=seg(blk))
                 if w.ffn == "mlp":
-                    k_igemm(M=T, N=hid, K=D, A=ws.y, lda=D, W=blk["fc1_w"], bias=blk["fc1_b"], flags=EP_BIAS | EP_GELU,
-                            out_op=ws.hd, ldo_op=hid)
-                    k_igemm(M=T, N=D, K=hid, A=ws.hd, lda=hid, W=blk["fc2_w"], bias=blk["fc2_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
-                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D)
+                    k_igemm(M=T, N=hid, k_alg=D, A=ws.y, W=blk["fc1_w"], bias=blk["fc1_b"], flags=EP_BIAS | EP_GELU,
+                            out_op=ws.hd, ldo_op=hid, **a_ln(blk, "fc1_w"))
+                    k_igemm(M=T, N=D, k_alg=hid, A=ws.hd, W=blk["fc2_w"], bias=blk["fc2_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
+                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, hid))
                 else:
-                    k_igemm(M=T, N=2 * hid, K=D, A=ws.y, lda=D, W=blk["w12_w"], bias=blk["w12_b"], flags=EP_BIAS | EP_SWIGLU,
-                            out_op=ws.hd, ldo_op=hid)
-                    k_igemm(M=T, N=D, K=hid, A=ws.hd, lda=hid, W=blk["w3_w"], bias=blk["w3_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
-                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D)
+                    k_igemm(M=T, N=2 * hid, k_alg=D, A=ws.y, W=blk["w12_w"], bias=blk["w12_b"], flags=EP_BIAS | EP_SWIGLU,
+                            out_op=ws.hd, ldo_op=hid, **a_ln(blk, "w12_w"))
+                    k_igemm(M=T, N=D, k_alg=hid, A=ws.hd, W=blk["w3_w"], bias=blk["w3_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
+                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, hid))
             if i in taps:  # shared final LayerNorm on the tap, cls row dropped (dinov2.py:337-340)
                 tap = ws.taps[taps.index(i)]
                 if not last and not fold:
                     # the next block's norm1 (block.py:84) reads the very rows this LayerNorm reads: one pass over x, two outputs with the
                     # same statistics -- norm1(x) for all T rows into ws.y, norm(x) without the cls rows into the tap
                     nb = w.blocks[i + 1]
-                    k_layernorm(ws.x, D, T, D, nb["ln1_w"], nb["ln1_b"], LN_EPS, out_op=ws.y, ld_op=D, weight2=w.norm_w, bias2=w.norm_b,
+                    k_layernorm(ws.x, D, T, D, nb["ln1_w"], nb["ln1_b"], LN_EPS, out_op=ws.y, ld_op=ldy, split_seg=seg(nb), weight2=w.norm_w, bias2=w.norm_b,
                                 out2_op=tap, ld2_op=tap.shape[1], out2_group=N, out2_skip=1, split_seg2=D if "proj" in w.split else 0)
                     ln1_done = True
                 else:

@@ -145,6 +145,10 @@ typedef struct ada_igemm_args {
                                tap_mask[p] (bit 3*(dy+1) + (dx+1)) names the touched taps; the kernel's k-loop for an N-tile walks the union of
                                its blocks' taps only: 36 C^2 MACs per coarse pixel instead of 160 C^2 for s = 4.  N / tap_cols <= 16.  0 = off */
     uint16_t tap_mask[16];
+    int32_t a_wrap;         /* PLAIN, > 0: weight-only split precision.  The A row holds a_wrap operand-typed elements and the contraction runs over
+                               K = 2 * a_wrap with the A walk starting over at k = a_wrap, against weights packed [w_hi | w_lo] (w_hi = round(w),
+                               w_lo = round(w - w_hi)):  x w_hi + x w_lo  -- the weight's rounding error is gone, the activation's stays
+                               (used where the activation is produced in the operand type anyway: attention output, SwiGLU hidden).  0 = off */
 } ada_igemm_args;
 
 int ada_igemm(const ada_igemm_args* args, void* stream);

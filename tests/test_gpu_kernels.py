@@ -206,6 +206,28 @@ def test_subpixel_conv_matches_conv_of_conv_transpose(hip, forced_tile, s, Ci, C
     assert float(border.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K,cfg", [(300, 200, 128, -1), (2740, 1152, 384, -1), (1000, 512, 1024, 3), (515, 256, 256, 4)])
+def test_igemm_weight_only_split(hip, forced_tile, M, N, K, cfg):
+    """ada_igemm_args.a_wrap: a plain operand-typed activation walked twice against [w_hi | w_lo] weights = x w to fp32 weight accuracy (the
+    activation's own rounding is the caller's: here x is exactly representable).  Used for proj / fc2 / w3 of the split-precision blocks."""
+    op = _op(hip)
+    x = _rand(M, K, seed=51).to(op)
+    w = _rand(N, K, seed=52) * K ** -0.5
+    b = _rand(N, seed=53)
+    w_hi = w.to(op)
+    wp = torch.cat([w_hi, (w - w_hi.float()).to(op)], dim=1).contiguous()
+    out = torch.zeros(M, N, device=DEV)
+    if cfg >= 0:
+        forced_tile(cfg, 0)
+    hip.igemm(M=M, N=N, K=2 * K, A=x.to(DEV), lda=K, a_wrap=K, W=wp.to(DEV), bias=b.to(DEV), flags=hip.EP_BIAS, out_f32=out, ldo_f32=N)
+    ref = x.double() @ w.double().T + b.double()
+    single = x.float() @ w_hi.float().T + b
+    e_split = float((out.cpu().double() - ref).abs().mean() / ref.abs().mean())
+    e_single = float((single.double() - ref).abs().mean() / ref.abs().mean())
+    print(f"weight-only split {M}x{N}x{K}: rel-L1 {e_split:.2e} (single operands: {e_single:.2e})")
+    assert e_split < (2e-6 if op == torch.float16 else 2e-5) and e_split < 0.05 * e_single
+
+
 def test_layernorm_second_output_drops_cls_rows(hip):
     """One pass, two normalised outputs of the same rows: all rows with (gain, bias) 1 -> the next block's LN1; the rows of every group of N
     but the first with (gain, bias) 2, compacted -> the tap LayerNorm (DA2/dinov2.py:337-340)."""

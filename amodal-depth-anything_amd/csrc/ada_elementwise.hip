@@ -2,6 +2,7 @@
 // resize (align_corners=True) with fused skip add.  See include/ada_hip.h for the reference call sites.
 // All of them move each byte once with 16-byte (fp32) / 8-byte (operand) accesses; row statistics use
 // wavefront shuffles only (one wave per row, no LDS).
+#include <mutex>
 #include "ada_common.h"
 
 namespace {
@@ -378,6 +379,147 @@ __global__ __launch_bounds__(256) void bilinear_tiled_kernel(BilinearArgs p, int
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 convolution of an align-corners up-sampled map, with the channel mixing done BEFORE the resize (ada_tapsum_resize_fwd).
+//   conv3x3(bilinear_ac(z))[Y, X, co] = b[co] + sum over taps t = (dy, dx) of  bilinear_ac(W_t z)[Y + dy - 1, X + dx - 1, co]
+// (a 1x1 channel mix commutes with a per-channel resample; positions outside the fine grid are the convolution's zero padding and drop out,
+// constant terms included).  The nine tap maps T[:, t*C + co] = W_t z live on the COARSE grid -- one GEMM with N = 9 C, a quarter of the MACs
+// of the 3x3 convolution on the 2x finer grid -- and this kernel gathers them: per output element 9 taps x 4 bilinear corners.
+// One workgroup per 8 x 16 output tile and all C <= 128 channels; the coarse patch under the tile's halo is staged through LDS one tap row
+// (three taps) at a time by global_load_lds; thread (pixel slot, 4-channel group) keeps its 16 output pixels' sums in registers.
+constexpr int TS_TH = 8, TS_TW = 16;
+
+struct TapSumArgs {
+    const void* in;      // [B * hi * wi, ld_in] operand-typed or fp32, columns t * C + c
+    long ld_in;
+    int batch, hi, wi, ho, wo, C;
+    float sy, sx;
+    const float* bias;   // [C] or null
+    float* out;          // [B * ho * wo, ld_out] fp32
+    long ld_out;
+    int ph, pw;          // patch extent (source pixels), maximised over all tiles by the host
+};
+
+// acc += w * (float)h.lo / h.hi with h a packed pair of operand-typed values: v_fma_mix_f32 reads the half directly (no v_cvt; hipcc's SLP
+// vectoriser turns the plain C++ form into v_cvt_f32_f16 + v_pk_fma_f32, 2.5 x the issue cycles)
+ADA_DEV void fma_mix_lo(float& acc, float w, uint32_t h) {
+#ifdef ADA_OPERAND_BF16
+    acc += w * __builtin_bit_cast(float, h << 16);
+#else
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(acc) : "v"(w), "v"(h));
+#endif
+}
+ADA_DEV void fma_mix_hi(float& acc, float w, uint32_t h) {
+#ifdef ADA_OPERAND_BF16
+    acc += w * __builtin_bit_cast(float, h & 0xffff0000u);
+#else
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(acc) : "v"(w), "v"(h));
+#endif
+}
+
+template <int C, typename TIN>
+__global__ __launch_bounds__(256) void tapsum_resize_kernel(TapSumArgs p) {
+    constexpr int ES = (int)sizeof(TIN);     // 2: operand-typed tap maps, 4: fp32 tap maps
+    extern __shared__ __attribute__((aligned(16))) char ts_smem[];
+    __shared__ float4 rowinfo[TS_TH + 2];    // per fine row of the halo: (byte offset of source row y0 in a tap's patch, of y1, ly1, valid)
+    __shared__ float4 colinfo[TS_TW + 2];    // per fine column: (byte offset of source column x0, of x1, lx1, valid)
+    constexpr int LPP = C * ES / 16;         // 16-byte lanes per source pixel and tap: 4 ... 32
+    constexpr int PPP = 256 / LPP;           // pixels staged per workgroup pass
+    constexpr int NG = C / 4;                // 4-channel groups
+    constexpr int PIXB = C * ES;             // bytes per pixel and tap in LDS
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = tid & 31, psub = tid >> 5;           // compute role: channel group (idle when >= NG), pixel slot
+    const int b = blockIdx.z;
+    const int tx0 = blockIdx.x * TS_TW, ty0 = blockIdx.y * TS_TH;
+    const int yf = ty0 > 0 ? ty0 - 1 : 0, xf = tx0 > 0 ? tx0 - 1 : 0;
+    const int py0 = (int)(p.sy * (float)yf), px0 = (int)(p.sx * (float)xf);   // top-left source pixel of the patch
+    const int npix = p.ph * p.pw;
+    const int tapbytes = ((npix + PPP - 1) / PPP) * PPP * PIXB;
+    if (tid < TS_TH + 2) {
+        const int Y = ty0 - 1 + tid;
+        const bool ok = Y >= 0 && Y < p.ho;
+        const float f = p.sy * (float)(ok ? Y : 0);
+        const int y0 = (int)f, y1 = y0 + (y0 < p.hi - 1 ? 1 : 0);
+        rowinfo[tid] = make_float4(__builtin_bit_cast(float, (y0 - py0) * p.pw * PIXB), __builtin_bit_cast(float, (y1 - py0) * p.pw * PIXB), f - (float)y0, ok ? 1.0f : 0.0f);
+    } else if (tid >= 64 && tid < 64 + TS_TW + 2) {
+        const int i = tid - 64, X = tx0 - 1 + i;
+        const bool ok = X >= 0 && X < p.wo;
+        const float f = p.sx * (float)(ok ? X : 0);
+        const int x0 = (int)f, x1 = x0 + (x0 < p.wi - 1 ? 1 : 0);
+        colinfo[i] = make_float4(__builtin_bit_cast(float, (x0 - px0) * PIXB), __builtin_bit_cast(float, (x1 - px0) * PIXB), f - (float)x0, ok ? 1.0f : 0.0f);
+    }
+    float4 acc[TS_TH * TS_TW / 8];
+#pragma unroll
+    for (int it = 0; it < TS_TH * TS_TW / 8; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int spx = tid / LPP, sl = tid % LPP;         // staging role: pixel inside a pass, 16-byte piece of its C channels
+    const long img = (long)b * p.hi;
+    const unsigned lds_g = (unsigned)(size_t)ts_smem + (unsigned)(g * 4 * ES);
+    for (int dy = 0; dy < 3; ++dy) {
+        // ---- stage the three taps (dy, 0..2) of the patch: LDS [tap][pixel][C] -------------------------------------------
+        __syncthreads();     // the previous tap row has been consumed (and rowinfo / colinfo are written)
+        for (int base = 0; base < npix; base += PPP) {
+            int pp = base + spx;
+            if (pp >= npix) pp = npix - 1;
+            const int r = pp / p.pw, c = pp - r * p.pw;
+            int yy = py0 + r, xx = px0 + c;
+            if (yy > p.hi - 1) yy = p.hi - 1;
+            if (xx > p.wi - 1) xx = p.wi - 1;
+            const TIN* src = (const TIN*)p.in + ((img + yy) * p.wi + xx) * p.ld_in + dy * 3 * C + sl * (16 / ES);
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + t * C),
+                                                 (__attribute__((address_space(3))) void*)(ts_smem + t * tapbytes + base * PIXB + wave * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (g < NG) {
+#pragma unroll
+            for (int it = 0; it < TS_TH * TS_TW / 8; ++it) {
+                const int py = it >> 1, px = (it & 1) * 8 + psub;
+                const float4 ri = rowinfo[py + dy];
+                if (ri.w == 0.0f) continue;                       // fine row outside the image: zero padding (workgroup-uniform)
+                const unsigned r0 = lds_g + __builtin_bit_cast(unsigned, ri.x), r1 = lds_g + __builtin_bit_cast(unsigned, ri.y);
+                const float ly1 = ri.z, ly0 = 1.0f - ly1;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const float4 ci = colinfo[px + t];
+                    const unsigned c0 = __builtin_bit_cast(unsigned, ci.x) + (unsigned)(t * tapbytes), c1 = __builtin_bit_cast(unsigned, ci.y) + (unsigned)(t * tapbytes);
+                    const float lx1 = ci.z * ci.w, lx0 = (1.0f - ci.z) * ci.w;      // a fine column outside the image contributes nothing
+                    const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+                    if constexpr (ES == 2) {
+                        const u32x2 v00 = *(const __attribute__((address_space(3))) u32x2*)(size_t)(r0 + c0), v01 = *(const __attribute__((address_space(3))) u32x2*)(size_t)(r0 + c1);
+                        const u32x2 v10 = *(const __attribute__((address_space(3))) u32x2*)(size_t)(r1 + c0), v11 = *(const __attribute__((address_space(3))) u32x2*)(size_t)(r1 + c1);
+                        fma_mix_lo(acc[it].x, w00, v00[0]); fma_mix_hi(acc[it].y, w00, v00[0]); fma_mix_lo(acc[it].z, w00, v00[1]); fma_mix_hi(acc[it].w, w00, v00[1]);
+                        fma_mix_lo(acc[it].x, w01, v01[0]); fma_mix_hi(acc[it].y, w01, v01[0]); fma_mix_lo(acc[it].z, w01, v01[1]); fma_mix_hi(acc[it].w, w01, v01[1]);
+                        fma_mix_lo(acc[it].x, w10, v10[0]); fma_mix_hi(acc[it].y, w10, v10[0]); fma_mix_lo(acc[it].z, w10, v10[1]); fma_mix_hi(acc[it].w, w10, v10[1]);
+                        fma_mix_lo(acc[it].x, w11, v11[0]); fma_mix_hi(acc[it].y, w11, v11[0]); fma_mix_lo(acc[it].z, w11, v11[1]); fma_mix_hi(acc[it].w, w11, v11[1]);
+                    } else {
+                        const f32x4 v00 = *(const __attribute__((address_space(3))) f32x4*)(size_t)(r0 + c0), v01 = *(const __attribute__((address_space(3))) f32x4*)(size_t)(r0 + c1);
+                        const f32x4 v10 = *(const __attribute__((address_space(3))) f32x4*)(size_t)(r1 + c0), v11 = *(const __attribute__((address_space(3))) f32x4*)(size_t)(r1 + c1);
+                        acc[it].x += w00 * v00[0] + w01 * v01[0] + w10 * v10[0] + w11 * v11[0];
+                        acc[it].y += w00 * v00[1] + w01 * v01[1] + w10 * v10[1] + w11 * v11[1];
+                        acc[it].z += w00 * v00[2] + w01 * v01[2] + w10 * v10[2] + w11 * v11[2];
+                        acc[it].w += w00 * v00[3] + w01 * v01[3] + w10 * v10[3] + w11 * v11[3];
+                    }
+                }
+            }
+        }
+    }
+    if (g >= NG) return;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias4 = ((const float4*)p.bias)[g];
+#pragma unroll
+    for (int it = 0; it < TS_TH * TS_TW / 8; ++it) {
+        const int y = ty0 + (it >> 1), x = tx0 + (it & 1) * 8 + psub;
+        if (y >= p.ho || x >= p.wo) continue;
+        float4 r = acc[it];
+        r.x += bias4.x; r.y += bias4.y; r.z += bias4.z; r.w += bias4.w;
+        store_f32_bil(p.out + (((long)b * p.ho + y) * p.wo + x) * p.ld_out + 4 * g, r);
+    }
+}
+
 // Bicubic resample of the learned position table to another patch grid (reference DA2/dinov2.py:199-230: F.interpolate(mode="bicubic",
 // antialias=False, scale_factor=...), i.e. ATen's upsample_bicubic2d with align_corners=False): cubic-convolution weights with A = -0.75,
 // source coordinate (dst + 0.5) * (1 / scale_factor) - 0.5 (not clamped), tap indices clamped to the grid.  One thread per (output
@@ -509,6 +651,61 @@ extern "C" int ada_layernorm_fwd(const float* in, int64_t ld_in, int32_t rows_ou
     a.out_op = out_op; a.ld_op = ld_op; a.map_op = map_op; a.map_h = map_h; a.map_w = map_w; a.relu = relu;
     a.out_f32 = out_f32; a.ld_f32 = ld_f32; a.split_seg = split_seg;
     return ada_layernorm_ex(&a, stream);
+}
+
+extern "C" int ada_tapsum_resize_fwd(const void* in, int32_t in_dtype, int64_t ld_in, int32_t batch, int32_t hi, int32_t wi, int32_t ho, int32_t wo, int32_t channels,
+                                     const float* bias, float* out, int64_t ld_out, void* stream) {
+    ADA_REQUIRE(in_dtype == ADA_DT_F32 || in_dtype == ADA_OP_DTYPE, ADA_EINVAL, "ada_tapsum_resize_fwd: in_dtype must be fp32 or the library's operand type");
+    const bool f32in = in_dtype == ADA_DT_F32;
+    ADA_REQUIRE(in && out, ADA_EINVAL, "ada_tapsum_resize_fwd: null pointer");
+    ADA_REQUIRE(batch > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0, ADA_EINVAL, "ada_tapsum_resize_fwd: bad shape");
+    ADA_REQUIRE(channels == 32 || channels == 64 || channels == 128, ADA_EUNSUPPORTED, "ada_tapsum_resize_fwd: %d channels (supported: 32, 64, 128)", channels);
+    ADA_REQUIRE(ld_in >= 9L * channels && ld_in % 8 == 0 && ((uintptr_t)in % 16) == 0, ADA_EINVAL, "ada_tapsum_resize_fwd: in must be 16-byte aligned with ld_in >= 9 * channels, ld_in %% 8 == 0");
+    ADA_REQUIRE(ld_out >= channels && ld_out % 4 == 0 && ((uintptr_t)out % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0), ADA_EINVAL, "ada_tapsum_resize_fwd: out / bias alignment");
+    ADA_REQUIRE(ho <= 65535 * TS_TH && batch <= 65535, ADA_EUNSUPPORTED, "ada_tapsum_resize_fwd: grid limits");
+    TapSumArgs p;
+    p.in = in; p.ld_in = ld_in; p.batch = batch; p.hi = hi; p.wi = wi; p.ho = ho; p.wo = wo; p.C = channels;
+    p.sy = ho > 1 ? (float)(hi - 1) / (float)(ho - 1) : 0.0f;
+    p.sx = wo > 1 ? (float)(wi - 1) / (float)(wo - 1) : 0.0f;
+    p.bias = bias; p.out = out; p.ld_out = ld_out;
+    // patch extent under a tile's halo: the same fp32 expressions the kernel evaluates, maximised over the tiles
+    auto extent = [](float sc, int n_in, int n_out, int tile) {
+        int best = 1;
+        for (int t0 = 0; t0 < n_out; t0 += tile) {
+            const int first = t0 > 0 ? t0 - 1 : 0;
+            const int last = t0 + tile < n_out - 1 ? t0 + tile : n_out - 1;
+            int hi_tap = (int)(sc * (float)last) + 1;
+            if (hi_tap > n_in - 1) hi_tap = n_in - 1;
+            const int e = hi_tap - (int)(sc * (float)first) + 1;
+            if (e > best) best = e;
+        }
+        return best;
+    };
+    p.ph = extent(p.sy, hi, ho, TS_TH);
+    p.pw = extent(p.sx, wi, wo, TS_TW);
+    const int es = f32in ? 4 : 2;
+    const int ppp = 256 / (channels * es / 16);
+    const long tapbytes = (((long)p.ph * p.pw + ppp - 1) / ppp) * ppp * channels * es;
+    ADA_REQUIRE(3 * tapbytes <= 150 * 1024, ADA_EUNSUPPORTED, "ada_tapsum_resize_fwd: the source patch of a tile (%d x %d pixels) does not fit LDS -- an up-sampling is expected", p.ph, p.pw);
+    static std::once_flag once;
+    std::call_once(once, []() {
+        for (const void* k : {(const void*)tapsum_resize_kernel<32, op_t>, (const void*)tapsum_resize_kernel<64, op_t>, (const void*)tapsum_resize_kernel<128, op_t>,
+                              (const void*)tapsum_resize_kernel<32, float>, (const void*)tapsum_resize_kernel<64, float>, (const void*)tapsum_resize_kernel<128, float>})
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) (void)hipGetLastError();
+    });
+    const dim3 grid((unsigned)((wo + TS_TW - 1) / TS_TW), (unsigned)((ho + TS_TH - 1) / TS_TH), (unsigned)batch);
+#define ADA_TS_LAUNCH(CH, T) hipLaunchKernelGGL((tapsum_resize_kernel<CH, T>), grid, dim3(256), (size_t)(3 * tapbytes), (hipStream_t)stream, p)
+    if (f32in) {
+        if (channels == 128) ADA_TS_LAUNCH(128, float);
+        else if (channels == 64) ADA_TS_LAUNCH(64, float);
+        else ADA_TS_LAUNCH(32, float);
+    } else {
+        if (channels == 128) ADA_TS_LAUNCH(128, op_t);
+        else if (channels == 64) ADA_TS_LAUNCH(64, op_t);
+        else ADA_TS_LAUNCH(32, op_t);
+    }
+#undef ADA_TS_LAUNCH
+    return ada_check_launch("ada_tapsum_resize_fwd");
 }
 
 extern "C" int ada_patchify(const float* x, const float* guide, int32_t batch, int32_t cg, int32_t height, int32_t width,

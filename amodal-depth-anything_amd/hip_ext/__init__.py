@@ -29,7 +29,7 @@ ACT_NONE, ACT_SIGMOID, ACT_RELU = 0, 1, 2
 EXPORTS = (
     "ada_abi_version", "ada_operand_dtype", "ada_last_error", "ada_igemm", "ada_attention_fwd",
     "ada_rowstats_finalize", "ada_pos_embed_resize", "ada_layernorm_fwd", "ada_layernorm_ex", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
-    "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd", "ada_dpt_tail_fwd",
+    "ada_minmax_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd", "ada_dpt_tail_fwd", "ada_tapsum_resize_fwd",
     "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
     "ada_debug_set_timestamps", "ada_debug_set_attention_variant", "ada_debug_count_saturated",
 )
@@ -135,6 +135,8 @@ def load(path: Optional[str] = None):
     lib.ada_dpt_tail_fwd.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                      c_float, c_int32, c_void_p, c_void_p]
     lib.ada_dpt_tail_fwd.restype = c_int
+    lib.ada_tapsum_resize_fwd.argtypes = [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p]
+    lib.ada_tapsum_resize_fwd.restype = c_int
     lib.ada_depth_eval_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_float, c_float, c_void_p, c_void_p]
     lib.ada_depth_eval_fwd.restype = c_int
     for name in ("ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_set_attention_variant"):
@@ -327,6 +329,18 @@ def dpt_tail(inp, ld_in, batch, hi, wi, ho, wo, cp, w, bias, tail_w, tail_b, tai
                                    _dev(out, "out", torch.float32), _stream()), "ada_dpt_tail_fwd")
     if ev is not None:
         _timer.stop("dpt_tail", ev, 2.0 * batch * ho * wo * 32 * 9 * cp)
+
+
+def tapsum_resize(inp, ld_in, batch, hi, wi, ho, wo, channels, bias, out, ld_out):
+    """conv3x3 of an align-corners up-sampling from the nine coarse tap maps (ada_tapsum_resize_fwd)."""
+    ev = _timer.start() if (_timer is not None and _timer.active) else None
+    if inp.dtype not in (torch.float32, operand_dtype()):
+        raise HipExtError(f"tapsum_resize: tap maps must be fp32 or {operand_dtype()}, got {inp.dtype}")
+    code = DT_F32 if inp.dtype == torch.float32 else (DT_F16 if inp.dtype == torch.float16 else DT_BF16)
+    _check(load().ada_tapsum_resize_fwd(_dev(inp, "in"), code, ld_in, batch, hi, wi, ho, wo, channels, _opt(bias, "bias", torch.float32),
+                                        _dev(out, "out", torch.float32), ld_out, _stream()), "ada_tapsum_resize_fwd")
+    if ev is not None:
+        _timer.stop("tapsum_resize", ev, 2.0 * 36 * batch * ho * wo * channels)
 
 
 def minmax(inp, minmax_out):

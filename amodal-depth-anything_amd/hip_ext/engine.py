@@ -38,6 +38,7 @@ from . import debug_epoch, instrumented, operand_dtype
 from . import patchify as k_patchify
 from . import pos_embed_resize as k_pos_embed_resize
 from . import rowstats_finalize as k_rowstats_finalize
+from . import tapsum_resize as k_tapsum_resize
 from . import write_cls as k_write_cls
 
 _probe = None   # list of (label, device counter) while DepthEngine.saturation_report runs, else None
@@ -77,6 +78,13 @@ FUSED_TAIL = os.environ.get("ADA_FUSED_TAIL", "1") == "1"
 # the up-sampled maps L[0] / L[1] are never written.  Exact in real arithmetic, weights composed in fp64 when they are packed.
 # ADA_SUBPIXEL=0 keeps the two launches (A/B; also the path of every split-precision level).
 SUBPIXEL = os.environ.get("ADA_SUBPIXEL", "1") == "1"
+# output_conv1 in front of its resize (round 4): path_1 = resize_x2(out_conv(RCU2(...))) (util/blocks.py:140-146, out_conv already commuted in front of
+# the resize) feeds scratch.output_conv1, a 3x3 convolution (DA2/dpt.py:192-193).  A 1x1 channel mix commutes with a per-channel resample, so
+#   conv3x3(resize(z)) = b + sum over the 9 taps t of  shift_t(resize(W_t z)),   z = out_conv(u):   W_t z = (W_t W_out) u + W_t b_out
+# -- ONE GEMM over the 148^2 grid with N = 9 * features / 2 (0.41 TFLOP at ViT-L bs = 32 instead of out_conv 0.09 + output_conv1 1.65) whose nine
+# operand-typed tap maps ada_tapsum_resize_fwd gathers (9 taps x 4 bilinear corners per output element; a tap whose position falls into the
+# zero padding drops out whole, out_conv's bias included).  The up-sampled operand map p1 is never written.  ADA_OC1_COMMUTE=0: the old path.
+OC1_COMMUTE = int(os.environ.get("ADA_OC1_COMMUTE", "16"))     # 0: off; 16: operand-typed tap maps (default); 32: fp32 tap maps (no parity gain, slower)
 
 
 def fused_tail_applies(half, halfp, hi, ho, split):
@@ -329,6 +337,20 @@ class PackedWeights:
                     d[f"u{u}c{c}_b"] = b.contiguous()
             self.fuse.append(d)  # index k-1
         self.oc1_w, self.oc1_b = conv3(f32(s + "output_conv1.weight"), "oc1"), f32(s + "output_conv1.bias")
+        self.oc1c = None     # output_conv1 composed with refinenet1.out_conv, one 1x1 per tap: [9 * half, Fp] (+ the bias each tap map carries)
+        half_ = self.features // 2
+        if OC1_COMMUTE and "oc1" not in self.split and "out0" not in self.split and half_ in (32, 64, 128):
+            w1 = f32(s + "output_conv1.weight").double()                         # [half, F, 3, 3]
+            wo_ = f32(s + "refinenet1.out_conv.weight").double().reshape(self.features, self.features)   # [F(cm), F(ci)]
+            bo_ = f32(s + "refinenet1.out_conv.bias").double()
+            wt_ = w1.permute(2, 3, 0, 1).reshape(9 * half_, self.features)       # rows (tap, co), columns cm
+            # [w_hi | w_lo] (ada_igemm a_wrap): rounding the COMPOSED matrix to the operand type once is not harmless -- its error acts on the
+            # activation's large common-mode part coherently over all taps and positions and survives the resizes and convolutions behind it
+            # (oracle study: 5.3e-4 at the output of ViT-B from this rounding alone, against 1.0e-4 / 0.9e-4 for the two factors rounded
+            # separately; profiles/r04_g_output_conv1_commute.txt).  K = 2 * 256 on a GEMM that is bound by its 1.6 GB of output anyway.
+            wc_ = (wt_ @ wo_).float()
+            wc_hi = wc_.to(op)
+            self.oc1c = dict(w=torch.cat([wc_hi, (wc_ - wc_hi.float()).to(op)], dim=1).contiguous(), b=(wt_ @ bo_).float().contiguous())
         self.oc2_w, self.oc2_b = conv3(f32(s + "output_conv2.0.weight"), "oc2"), f32(s + "output_conv2.0.bias")
         self.tail_w = f32(s + "output_conv2.2.weight").reshape(-1).contiguous()
         self.tail_b = float(f32(s + "output_conv2.2.bias").reshape(-1)[0].item())
@@ -430,7 +452,9 @@ class Workspace:
         self.zf = self.rnx
         g0 = self.grid[0]
         self.g296 = (2 * g0[0], 2 * g0[1])
-        self.p1 = z(B, self.g296[0] + 2, self.g296[1] + 2, mm("oc1") * Fp)
+        self.p1 = None if pw_.oc1c is not None else z(B, self.g296[0] + 2, self.g296[1] + 2, mm("oc1") * Fp)
+        # the nine tap maps of output_conv1 on the level-0 grid
+        self.tmaps = z(rows[0], 9 * (Fch // 2), dtype=torch.float32 if OC1_COMMUTE == 32 else op) if pw_.oc1c is not None else None
         half = Fch // 2
         self.half, self.halfp = half, _r64(half)
         self.oc1 = lvl0.view(B * self.g296[0] * self.g296[1], half)
@@ -567,7 +591,7 @@ class DepthEngine:
         if not use or instrumented() or torch.cuda.is_current_stream_capturing():
             return self._forward(x, guide, norm)
         # the kernel variant / tile override / fused-tail switch in force at capture time are baked into the graph
-        key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device), debug_epoch(), FUSED_TAIL, SUBPIXEL, norm)
+        key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device), debug_epoch(), FUSED_TAIL, SUBPIXEL, OC1_COMMUTE, norm)
         with self._lock:
             g = self._graphs.get(key)
             if g is not None:
@@ -780,6 +804,8 @@ class DepthEngine:
         for i in (3, 2, 1, 0):
             fw = w.fuse[i]
             rcu(i, fw, 2, s_pad, s_f32, out_op=ws.u[i], ldo_op=ws.u[i].shape[1], split_seg=S(f"out{i}", Fp))
+            if i == 0 and w.oc1c is not None:
+                break     # refinenet1.out_conv is part of output_conv1's tap maps (below)
             k_igemm(M=rows[i], N=Fch, k_alg=Fch, A=ws.u[i], W=fw["out_w"], bias=fw["out_b"], flags=EP_BIAS, **self._kdup(ws.u[i].shape[1], fw["out_w"]),
                     out_f32=ws.zf[i], ldo_f32=Fch)
             if i > 0:
@@ -789,10 +815,15 @@ class DepthEngine:
                            out_f32=ws.s[j], ld_f32=Fch, out_op=ws.sr[j], ld_op=ws.sr[j].shape[3], map_op=MAP_PAD, relu=True, split_seg=S(f"rcu{j}", Fp))
                 s_f32, s_pad = ws.s[j], ws.sr[j]
         g2 = ws.g296
-        k_bilinear(ws.zf[0], Fch, B, grid[0][0], grid[0][1], g2[0], g2[1], Fch, out_op=ws.p1, ld_op=ws.p1.shape[3], map_op=MAP_PAD, split_seg=S("oc1", Fp))
-
-        # ---- output_conv1 -> resize to (14 ph, 14 pw) -> output_conv2 (3x3, ReLU, 1x1, activation) (dpt.py:193-195) ----
-        self._conv3(ws.p1, w.oc1_w, B * g2[0] * g2[1], ws.half, g2, cin=Fch, bias=w.oc1_b, flags=EP_BIAS, out_f32=ws.oc1, ldo_f32=ws.half)
+        # ---- resize x2 -> output_conv1 (dpt.py:192-193) -> resize to (14 ph, 14 pw) -> output_conv2 (3x3, ReLU, 1x1, activation) (:194-195) ----
+        if w.oc1c is not None:
+            ntap = 9 * ws.half
+            tout = dict(out_f32=ws.tmaps, ldo_f32=ntap) if ws.tmaps.dtype == torch.float32 else dict(out_op=ws.tmaps, ldo_op=ntap)
+            k_igemm(M=rows[0], N=ntap, K=2 * Fp, a_wrap=Fp, k_alg=Fch, A=ws.u[0], lda=Fp, W=w.oc1c["w"], bias=w.oc1c["b"], flags=EP_BIAS, **tout)
+            k_tapsum_resize(ws.tmaps, ntap, B, grid[0][0], grid[0][1], g2[0], g2[1], ws.half, w.oc1_b, ws.oc1, ws.half)
+        else:
+            k_bilinear(ws.zf[0], Fch, B, grid[0][0], grid[0][1], g2[0], g2[1], Fch, out_op=ws.p1, ld_op=ws.p1.shape[3], map_op=MAP_PAD, split_seg=S("oc1", Fp))
+            self._conv3(ws.p1, w.oc1_w, B * g2[0] * g2[1], ws.half, g2, cin=Fch, bias=w.oc1_b, flags=EP_BIAS, out_f32=ws.oc1, ldo_f32=ws.half)
         out = torch.empty(B, 1, ws.H, ws.W, dtype=torch.float32, device=ws.oc1.device)
         if ws.fused_tail:
             k_dpt_tail(ws.oc1, ws.half, B, g2[0], g2[1], ws.H, ws.W, ws.halfp, w.oc2_w, w.oc2_b, w.tail_w, w.tail_b, self.final_act, out)

@@ -224,6 +224,21 @@ typedef struct ada_layernorm_args {
 int ada_layernorm_ex(const ada_layernorm_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 3x3 convolution of an align-corners bilinear up-sampling with the channel mixing moved in front of the resize:
+ *   scratch.output_conv1( F.interpolate(refinenet1 output, x2, bilinear, align_corners=True) )      DA2/dpt.py:192-193, util/blocks.py:144-146
+ * A 1x1 channel mix commutes with a per-channel resample, so
+ *   conv3x3(resize(z))[Y, X, co] = b[co] + sum over the taps t = (dy, dx) whose position (Y + dy - 1, X + dx - 1) lies inside the fine grid of
+ *                                  resize(W_t z)[Y + dy - 1, X + dx - 1, co]
+ * in: [B * hi * wi, ld_in], fp32 or operand-typed (in_dtype = ADA_DT_F32 / the library's operand type), column t * channels + co = (W_t z)[co] on the COARSE grid (one ada_igemm with N = 9 * channels; the
+ *     caller composes W_t with whatever 1x1 convolution precedes the resize -- refinenet1.out_conv -- and puts that convolution's bias, seen
+ *     through W_t, into the GEMM's bias: a tap that falls into the zero padding then drops out whole, as it must).
+ * out: fp32 [B * ho * wo, ld_out].  channels in {32, 64, 128}; an up-sampling is expected (the patch under an 8 x 16 tile must fit LDS).
+ * A quarter of the 3x3 convolution's MACs on the 2x finer grid, and the up-sampled operand map is never written.
+ * ---------------------------------------------------------------------------------------- */
+int ada_tapsum_resize_fwd(const void* in, int32_t in_dtype, int64_t ld_in, int32_t batch, int32_t hi, int32_t wi, int32_t ho, int32_t wo, int32_t channels,
+                          const float* bias, float* out, int64_t ld_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Patchify: the im2col half of the 14x14/stride-14 patch-embed convolutions
  * (DA2/dinov2_layers/patch_embed.py:76 for RGB, DA2/dinov2.py:239 for the guidance embed) with
  * the ImageNet normalisation of src/models/amodalsynthdrive/dav2.py:65 fused in.

@@ -228,6 +228,35 @@ def test_igemm_weight_only_split(hip, forced_tile, M, N, K, cfg):
     assert e_split < (2e-6 if op == torch.float16 else 2e-5) and e_split < 0.05 * e_single
 
 
+@pytest.mark.parametrize("B,C,Cin,hi,wi,ho,wo", [(2, 128, 256, 37, 37, 74, 74), (1, 64, 128, 20, 30, 40, 60), (3, 32, 64, 9, 11, 18, 22), (1, 128, 64, 10, 10, 25, 33),
+                                                 (1, 128, 256, 148, 148, 296, 296), (2, 64, 64, 1, 1, 2, 2), (1, 128, 128, 5, 7, 16, 15)])
+@pytest.mark.parametrize("tmap", ["f32", "op"])
+def test_tapsum_resize_is_conv3x3_of_the_upsampled_map(hip, B, C, Cin, hi, wi, ho, wo, tmap):
+    """ada_tapsum_resize_fwd on the nine coarse tap maps (W_t W_out) u + W_t b_out (one GEMM) == conv3x3(bilinear_ac(out_conv(u))) in fp32."""
+    op = _op(hip)
+    u = _rand(B, Cin, hi, wi, seed=61).to(op).float()
+    w_out = _rand(Cin, Cin, 1, 1, seed=62) * Cin ** -0.5
+    b_out = _rand(Cin, seed=63)
+    w1 = _rand(C, Cin, 3, 3, seed=64) * (9 * Cin) ** -0.5
+    b1 = _rand(C, seed=65)
+    ref = F.conv2d(F.interpolate(F.conv2d(u, w_out, b_out), size=(ho, wo), mode="bilinear", align_corners=True), w1, b1, padding=1)
+    wt = w1.double().permute(2, 3, 0, 1).reshape(9 * C, Cin)
+    wc = (wt @ w_out.double().reshape(Cin, Cin)).float()
+    bc = (wt @ b_out.double()).float()
+    A = u.permute(0, 2, 3, 1).reshape(-1, Cin).to(op).contiguous().to(DEV)
+    T = torch.zeros(B * hi * wi, 9 * C, dtype=op if tmap == "op" else torch.float32, device=DEV)
+    tout = dict(out_op=T, ldo_op=9 * C) if tmap == "op" else dict(out_f32=T, ldo_f32=9 * C)
+    hip.igemm(M=B * hi * wi, N=9 * C, K=Cin, A=A, lda=Cin, W=wc.to(op).to(DEV), bias=bc.to(DEV), flags=hip.EP_BIAS, **tout)
+    out = torch.full((B * ho * wo, C), float("nan"), device=DEV)
+    hip.tapsum_resize(T, 9 * C, B, hi, wi, ho, wo, C, b1.to(DEV), out, C)
+    got = out.view(B, ho, wo, C).permute(0, 3, 1, 2)
+    # operand rounding of the composed weights and of the nine tap maps: a few 1e-3 absolute on outputs of magnitude ~1
+    _close(got, ref, 4e-2 if op == torch.bfloat16 else 5e-3, rtol=2e-2 if op == torch.bfloat16 else 4e-3, what="tap-sum resize")
+    err = float((got.cpu() - ref).abs().mean() / ref.abs().mean())
+    print(f"tap-sum resize {B}x{C}x{hi}x{wi}->{ho}x{wo}: rel-L1 {err:.2e}")
+    assert err < (8e-3 if op == torch.bfloat16 else 1e-3)
+
+
 def test_layernorm_second_output_drops_cls_rows(hip):
     """One pass, two normalised outputs of the same rows: all rows with (gain, bias) 1 -> the next block's LN1; the rows of every group of N
     but the first with (gain, bias) 2, compacted -> the tap LayerNorm (DA2/dinov2.py:337-340)."""

@@ -83,6 +83,7 @@ struct LnArgs {
     int unshuffle_s;
     FastDiv dUnS;
     const float* tap_bias;   // [s*s*dim, 9]: bias contribution of coarse tap t to column (phase, c); subtracted where the tap falls outside the grid
+    int identity;            // 1: no normalisation (y = x): the kernel is then the un-shuffle / re-layout pass of a sub-pixel convolution's output
 };
 
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    const float mean = wave_sum(s) / (float)p.dim;
+    float mean = wave_sum(s) / (float)p.dim;
     float q = 0.0f;
 #pragma unroll
     for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
             q += (a * a + b * b) + (cc * cc + d * d);
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.dim + p.eps);
+    float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.dim + p.eps);
+    if (p.identity) { mean = 0.0f; rstd = 1.0f; }
     long orow = ro;
     if (p.out_op && p.map_op == ADA_MAP_PAD) orow = pad_row((uint32_t)ro, p.map_h, p.map_w, p.dMapW, p.dMapHW);
     const float4* w4 = (const float4*)p.weight;
@@ -155,17 +157,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            const float4 w = w4[c], bb = b4[c];
-            float4 y;
-            y.x = (v[i].x - mean) * rstd * w.x + bb.x;
-            y.y = (v[i].y - mean) * rstd * w.y + bb.y;
-            y.z = (v[i].z - mean) * rstd * w.z + bb.z;
-            y.w = (v[i].w - mean) * rstd * w.w + bb.w;
-            if (p.relu) {
+            float4 y = v[i];
+            if (!p.identity) {
+                const float4 w = w4[c], bb = b4[c];
+                y.x = (v[i].x - mean) * rstd * w.x + bb.x;
+                y.y = (v[i].y - mean) * rstd * w.y + bb.y;
+                y.z = (v[i].z - mean) * rstd * w.z + bb.z;
+                y.w = (v[i].w - mean) * rstd * w.w + bb.w;
+            }
+            if (p.relu == 1) {
                 y.x = __builtin_fmaxf(y.x, 0.f); y.y = __builtin_fmaxf(y.y, 0.f);
                 y.z = __builtin_fmaxf(y.z, 0.f); y.w = __builtin_fmaxf(y.w, 0.f);
             }
             if (p.out_f32) ((float4*)(p.out_f32 + (long)ro * p.ld_f32))[c] = y;
+            if (p.relu == 2) {   // ReLU on the operand-typed copy only (the fp32 copy feeds a residual add: util/blocks.py:57-80)
+                y.x = __builtin_fmaxf(y.x, 0.f); y.y = __builtin_fmaxf(y.y, 0.f);
+                y.z = __builtin_fmaxf(y.z, 0.f); y.w = __builtin_fmaxf(y.w, 0.f);
+            }
             if (p.out_op) store_op4_split(p.out_op + orow * p.ld_op, c, y, p.split_seg);
         }
     }
@@ -603,7 +611,8 @@ extern "C" int ada_rowstats_finalize(const float* partials, int32_t rows, int32_
 extern "C" int ada_layernorm_ex(const ada_layernorm_args* a, void* stream) {
     ADA_REQUIRE(a != nullptr, ADA_EINVAL, "ada_layernorm: null args");
     const int rows_out = a->rows_out, dim = a->dim;
-    ADA_REQUIRE(a->in && a->weight && a->bias, ADA_EINVAL, "ada_layernorm_fwd: null pointer");
+    ADA_REQUIRE(a->in && ((a->weight && a->bias) || a->identity), ADA_EINVAL, "ada_layernorm_fwd: null pointer");
+    ADA_REQUIRE(a->relu >= 0 && a->relu <= 2 && (a->identity == 0 || a->identity == 1) && !(a->identity && a->out2_op), ADA_EINVAL, "ada_layernorm: relu in 0..2, identity in 0..1 (no second output)");
     ADA_REQUIRE(a->out_op || a->out_f32 || a->out2_op, ADA_EINVAL, "ada_layernorm_fwd: no output buffer");
     ADA_REQUIRE(rows_out > 0 && dim > 0, ADA_EINVAL, "ada_layernorm_fwd: bad shape rows=%d dim=%d", rows_out, dim);
     ADA_REQUIRE(dim % 4 == 0 && dim <= LN_MAX_CHUNKS * 256, ADA_EUNSUPPORTED, "ada_layernorm_fwd: dim=%d must be a multiple of 4 and <= 1536", dim);
@@ -630,6 +639,7 @@ extern "C" int ada_layernorm_ex(const ada_layernorm_args* a, void* stream) {
         ADA_REQUIRE(a->out2_group == 0 || (a->out2_skip >= 0 && a->out2_skip < a->out2_group && rows_out % a->out2_group == 0), ADA_EINVAL, "ada_layernorm: bad out2 group/skip");
         ADA_REQUIRE(a->split_seg2 == 0 || (a->split_seg2 >= dim && a->split_seg2 % 4 == 0 && a->ld2_op >= 2L * a->split_seg2), ADA_EINVAL, "ada_layernorm: bad split_seg2");
     }
+    p.identity = a->identity;
     p.unshuffle_s = a->unshuffle_s; p.dUnS = make_fastdiv(a->unshuffle_s > 0 ? a->unshuffle_s : 1); p.tap_bias = a->tap_bias;
     if (a->unshuffle_s != 0) {
         ADA_REQUIRE(a->unshuffle_s > 0 && a->unshuffle_s <= 4 && a->group_in == 0 && a->map_h > 0 && a->map_w > 0 && a->map_h % a->unshuffle_s == 0 &&

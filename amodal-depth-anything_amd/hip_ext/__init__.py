@@ -65,7 +65,7 @@ class LayerNormArgs(ctypes.Structure):
         ("out_op", c_void_p), ("ld_op", c_int64), ("map_op", c_int32), ("map_h", c_int32), ("map_w", c_int32), ("relu", c_int32),
         ("out_f32", c_void_p), ("ld_f32", c_int64), ("split_seg", c_int32),
         ("weight2", c_void_p), ("bias2", c_void_p), ("out2_op", c_void_p), ("ld2_op", c_int64),
-        ("out2_group", c_int32), ("out2_skip", c_int32), ("split_seg2", c_int32), ("unshuffle_s", c_int32), ("tap_bias", c_void_p),
+        ("out2_group", c_int32), ("out2_skip", c_int32), ("split_seg2", c_int32), ("unshuffle_s", c_int32), ("tap_bias", c_void_p), ("identity", c_int32),
     ]
 
 
@@ -275,13 +275,14 @@ def attention(qkv: torch.Tensor, out: torch.Tensor, batch: int, n_tokens: int, h
 
 def layernorm(inp, ld_in, rows_out, dim, weight, bias, eps, *, group_in=0, skip=0, out_op=None, ld_op=0, map_op=MAP_PLAIN,
               map_h=0, map_w=0, relu=False, out_f32=None, ld_f32=0, split_seg=0, weight2=None, bias2=None, out2_op=None, ld2_op=0,
-              out2_group=0, out2_skip=0, split_seg2=0, unshuffle_s=0, tap_bias=None):
+              out2_group=0, out2_skip=0, split_seg2=0, unshuffle_s=0, tap_bias=None, identity=False):
     """ada_layernorm_ex (include/ada_hip.h): LayerNorm rows -> op-typed / fp32 output; optionally a second op-typed output with its own gain /
     bias (out2_*), optionally reading a sub-pixel convolution's [coarse pixel, s*s*dim] output in fine-pixel order (unshuffle_s, tap_bias)."""
     op = operand_dtype()
     a = LayerNormArgs()
     a.in_, a.ld_in, a.rows_out, a.dim, a.group_in, a.skip = _dev(inp, "in", torch.float32), ld_in, rows_out, dim, group_in, skip
-    a.weight, a.bias, a.eps = _dev(weight, "weight", torch.float32), _dev(bias, "bias", torch.float32), eps
+    a.weight, a.bias, a.eps = _opt(weight, "weight", torch.float32), _opt(bias, "bias", torch.float32), eps
+    a.identity = int(identity)
     a.out_op, a.ld_op, a.map_op, a.map_h, a.map_w, a.relu = _opt(out_op, "out_op", op), ld_op, map_op, map_h, map_w, int(relu)
     a.out_f32, a.ld_f32, a.split_seg = _opt(out_f32, "out_f32", torch.float32), ld_f32, split_seg
     a.weight2, a.bias2 = _opt(weight2, "weight2", torch.float32), _opt(bias2, "bias2", torch.float32)

@@ -111,9 +111,6 @@ def _r64(c: int) -> int:
     return (c + 63) // 64 * 64
 
 
-def first_is_split(split, i):
-    """Whether the 1x1 `projects[i]` feeding level i's transposed conv writes a split tensor (group "rs<i>" reads it): never merged then."""
-    return f"rs{i}" in split
 
 
 class PackedWeights:
@@ -302,14 +299,20 @@ class PackedWeights:
         self.rs0_w, self.rs0_b = convT(f32(h + "resize_layers.0.weight"), f32(h + "resize_layers.0.bias"), 4, "rs0")
         self.rs1_w, self.rs1_b = convT(f32(h + "resize_layers.1.weight"), f32(h + "resize_layers.1.bias"), 2, "rs1")
         self.rs3_w, self.rs3_b = conv3(f32(h + "resize_layers.3.weight"), "rs3"), f32(h + "resize_layers.3.bias")
-        self.sp = {}      # level -> merged sub-pixel convolution (amodal head, single-precision levels only)
-        if amodal_head and SUBPIXEL:
+        # level -> merged sub-pixel convolution (single-precision levels only): resize_layers[i] + input_projection[i][0] in the amodal head,
+        # resize_layers[i] + scratch.layer{i+1}_rn (no bias, util/blocks.py:20-24) in the raw head
+        self.sp = {}
+        if SUBPIXEL:
             from .functional import subpixel_merge
+            nxt = "ip" if amodal_head else "rn"
             for i, s_ in ((0, 4), (1, 2)):
-                if f"rs{i}" in self.split or f"ip{i}" in self.split or first_is_split(self.split, i):
+                if f"rs{i}" in self.split or f"{nxt}{i}" in self.split:
                     continue
-                wm, bias, tapb, masks = subpixel_merge(f32(f"{h}resize_layers.{i}.weight"), f32(f"{h}resize_layers.{i}.bias"),
-                                                       f32(f"{h}input_projection.{i}.0.weight"), f32(f"{h}input_projection.{i}.0.bias"), s_)
+                if amodal_head:
+                    w3_, b3_ = f32(f"{h}input_projection.{i}.0.weight"), f32(f"{h}input_projection.{i}.0.bias")
+                else:
+                    w3_, b3_ = f32(f"{h}scratch.layer{i + 1}_rn.weight"), None
+                wm, bias, tapb, masks = subpixel_merge(f32(f"{h}resize_layers.{i}.weight"), f32(f"{h}resize_layers.{i}.bias"), w3_, b3_, s_)
                 ci = wm.shape[2]
                 if ci % 64:
                     wm = F.pad(wm, (0, _r64(ci) - ci))
@@ -430,6 +433,8 @@ class Workspace:
             self.ipf = [z(B * g[0] * g[1], oc[i], dtype=torch.float32) for i, g in enumerate(self.grid)]
             self.L2 = [z(B, g[0] + 2, g[1] + 2, mm(f"rn{i}") * ocp[i]) for i, g in enumerate(self.grid)]
         self.rnx = [z(B * g[0] * g[1], Fch, dtype=torch.float32) for g in self.grid]
+        # raw head: [patch, s*s*features] fp32 output of a merged resize + layer_rn convolution, re-laid out into rnx / rnr by one pass
+        self.spf = {} if pw_.amodal_head else {i: z(B * self.grid[i][0] * self.grid[i][1], Fch, dtype=torch.float32) for i in pw_.sp}
         self.rnr = [z(B, g[0] + 2, g[1] + 2, mm(f"rcu{i}") * Fp) for i, g in enumerate(self.grid)]
         self.tmpa = [z(B, g[0] + 2, g[1] + 2, mm(f"rcu{i}") * Fp) for i, g in enumerate(self.grid)]
         # fp32 side buffers whose lifetimes do not overlap share storage (plain row buffers only: the zero-bordered operand tensors keep their own,
@@ -787,6 +792,17 @@ class DepthEngine:
 
         # ---- layerN_rn (blocks.py:20-24): fp32 copy for the residual adds + ReLU'd operand copy for conv1 ----
         for i in range(4):
+            if not w.amodal_head and i in w.sp:
+                # raw head: resize_layers[i] + layer{i+1}_rn as one sub-pixel convolution over the patch grid, then ONE re-layout pass: fine-pixel
+                # order, the transposed conv's bias taken out on the outermost ring, fp32 copy for the residual adds + ReLU'd operand copy
+                sp = w.sp[i]
+                ncol = sp["s"] * sp["s"] * Fch
+                self._conv3(ws.tp[i], sp["w"], P, ncol, (ph, pw), k_alg=sp["taps_per_col"] * oc[i], bias=sp["b"], flags=EP_BIAS,
+                            out_f32=ws.spf[i], ldo_f32=ncol, tap_cols=Fch, tap_mask=sp["masks"])
+                k_layernorm(ws.spf[i], ncol, rows[i], Fch, None, None, LN_EPS, identity=True, relu=2, out_f32=ws.rnx[i], ld_f32=Fch, out_op=ws.rnr[i],
+                            ld_op=ws.rnr[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], split_seg=S(f"rcu{i}", Fp),
+                            unshuffle_s=sp["s"], tap_bias=sp["tapb"])
+                continue
             self._conv3(layers[i], w.rn_w[i], rows[i], Fch, grid[i], cin=oc[i], flags=EP_RELU_OP, out_f32=ws.rnx[i], ldo_f32=Fch,
                         out_op=ws.rnr[i], ldo_op=ws.rnr[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], split_seg=S(f"rcu{i}", Fp))
 

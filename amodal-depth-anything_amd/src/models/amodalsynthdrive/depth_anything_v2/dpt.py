@@ -129,6 +129,7 @@ _FOLD_LN_DEFAULT = _os.environ.get("ADA_FOLD_LN", "0") == "1"
 #                                                               ResidualConvUnit convs makes ViT-G parity WORSE (1.13e-3 -> 1.31e-3).
 # round 4: + "oc1" (with the encoder's early blocks in split precision -- _RAW_VITG_ENC_SPLIT_BLOCKS -- the head's share shows again:
 # profiles/r04_e_raw_vitg_precision.txt)
+_SIGMOID_SPLIT = ("out1", "out2", "out3")
 _RAW_VITG_SPLIT = ("oc1", "oc2", "out", "rn1", "rn2", "rn3", "proj", "rs1", "rs3")
 
 
@@ -144,7 +145,10 @@ def _head_split_policy(mode, encoder, final_act):
         return frozenset()
     if mode == "auto":
         if final_act == "sigmoid" and encoder != "vits":
-            return frozenset()
+            # round 4: the 1x1 out_convs of refinenet2-4 in split precision -- the largest single group of the head's operand noise in the
+            # ViT-B / ViT-L oracle studies and all but free (K = features): worst fixture 9.25e-4 -> 6.9e-4, throughput unchanged
+            # (profiles/r04_h_sigmoid_head_out_conv_split.txt).  refinenet1's out_conv is part of output_conv1's tap maps (engine OC1_COMMUTE)
+            return frozenset(_SIGMOID_SPLIT)
         if final_act == "relu" and encoder == "vitg":
             return frozenset(_RAW_VITG_SPLIT)
         return frozenset(HEAD_GROUPS)

@@ -62,9 +62,11 @@ def _apply_outliers_(key: str, v: torch.Tensor) -> torch.Tensor:
 def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int = 0, tail: str = "normal") -> Dict[str, torch.Tensor]:
     """Overwrites every floating tensor of ``sd`` in place; returns ``sd``.  ``tail``: "normal" | "heavy" (outlier channels, see above)."""
     assert tail in ("normal", "heavy"), tail
-    for key, t in sd.items():
+
+    def fill(item):
+        key, t = item
         if not torch.is_floating_point(t):
-            continue
+            return
         g = _gen(key, seed)
         shape = tuple(t.shape)
         leaf = key.rsplit(".", 1)[-1]
@@ -91,8 +93,8 @@ def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int = 0, tail: str = "no
                 fan_in = shape[0]  # ConvTranspose2d [Cin, Cout, k, k], stride == k: Cin terms per output
             else:
                 fan_in = 1
-                for s in shape[1:]:
-                    fan_in *= s
+                for s_ in shape[1:]:
+                    fan_in *= s_
             gain = 1.0
             if "patch_embed_guidance" in key:
                 gain = 2.0
@@ -108,6 +110,19 @@ def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int = 0, tail: str = "no
         if tail == "heavy":
             v = _apply_outliers_(key, v)
         t.copy_(v.to(t.dtype))
+
+    # every tensor has its own generator, so the keys can be filled concurrently (torch releases the GIL inside randn): the ViT-G fixtures
+    # (1.1 G parameters) spend most of their test time here
+    items = list(sd.items())
+    big = sum(t.numel() for _, t in items) > (1 << 26)
+    if big:
+        from concurrent.futures import ThreadPoolExecutor
+        import os as _os
+        with ThreadPoolExecutor(max_workers=min(16, _os.cpu_count() or 1)) as ex:
+            list(ex.map(fill, items))
+    else:
+        for it in items:
+            fill(it)
     return sd
 
 

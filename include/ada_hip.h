@@ -220,6 +220,9 @@ typedef struct ada_layernorm_args {
     int32_t out2_group, out2_skip, split_seg2;
     int32_t unshuffle_s;
     const float* tap_bias;
+    int32_t identity;       /* 1: no normalisation, y = x (weight / bias may be NULL): with unshuffle_s the kernel is the re-layout pass behind a sub-pixel
+                               convolution whose consumer is not a LayerNorm (raw head: resize_layers[i] + layerN_rn).  relu: 0 none, 1 both outputs,
+                               2 the operand-typed output only (the fp32 copy is the pre-activation the ResidualConvUnit adds back, util/blocks.py:57-80) */
 } ada_layernorm_args;
 int ada_layernorm_ex(const ada_layernorm_args* args, void* stream);
 

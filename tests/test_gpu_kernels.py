@@ -204,6 +204,13 @@ def test_subpixel_conv_matches_conv_of_conv_transpose(hip, forced_tile, s, Ci, C
     border = outp.clone()
     border[:, 1:-1, 1:-1] = 0
     assert float(border.abs().max()) == 0.0
+    # (c) the raw head's consumer is not a LayerNorm: the same kernel as a re-layout pass (identity), fp32 pre-activation + ReLU'd operand copy
+    outp2 = torch.zeros(B, s * H + 2, s * W + 2, Co, dtype=op, device=DEV)
+    outf2 = torch.full((B * s * H * s * W, Co), float("nan"), device=DEV)
+    hip.layernorm(out, N, B * s * H * s * W, Co, None, None, 1e-6, identity=True, relu=2, out_f32=outf2, ld_f32=Co, out_op=outp2, ld_op=Co, map_op=hip.MAP_PAD,
+                  map_h=s * H, map_w=s * W, unshuffle_s=s, tap_bias=tapb.to(DEV))
+    _close(outf2.view(B, s * H, s * W, Co), ref.permute(0, 2, 3, 1), 2e-3, rtol=3e-3, what="re-layout pass, fp32 copy")
+    _close(outp2[:, 1:-1, 1:-1], F.relu(ref.permute(0, 2, 3, 1)), 4e-3, rtol=1e-2 if op == torch.bfloat16 else 4e-3, what="re-layout pass, ReLU'd operand copy")
 
 
 @pytest.mark.parametrize("M,N,K,cfg", [(300, 200, 128, -1), (2740, 1152, 384, -1), (1000, 512, 1024, 3), (515, 256, 256, 4)])

@@ -30,6 +30,16 @@ def per_family(path, counter):
     return out
 
 
+def csrc_digest():
+    """Digest of the kernel sources + build flags (csrc/build.py::_digest): bench.py refuses to quote traffic collected on other kernels."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ada_build", os.path.join(root, "amodal-depth-anything_amd", "csrc", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod._digest([])
+
+
 def main(fetch_csv, write_csv):
     f, w = per_family(fetch_csv, "FETCH_SIZE"), per_family(write_csv, "WRITE_SIZE")
     detail = {}
@@ -39,7 +49,7 @@ def main(fetch_csv, write_csv):
             continue
         detail[fam] = {"launches": n, "fetch_kib_raw": f[fam][1], "write_kib_raw": w[fam][1],
                        "bytes_per_launch": (2.0 * f[fam][1] + w[fam][1]) * 1024.0 / n}
-    res = {"collected": os.environ.get("ADA_COLLECTED", "unstamped"),
+    res = {"collected": os.environ.get("ADA_COLLECTED", "unstamped"), "csrc_digest": csrc_digest(),
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1` (2 forwards, ViT-L bs=32); "
                    "KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B); WRITE_SIZE uncalibrated; "
                    "L2-fabric requests, Infinity-Cache hits included.  Algorithmic bytes per igemm launch (operands + outputs once) average "

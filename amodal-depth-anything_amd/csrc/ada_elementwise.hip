@@ -464,6 +464,11 @@ __global__ __launch_bounds__(256) void tapsum_resize_kernel(TapSumArgs p) {
     const int spx = tid / LPP, sl = tid % LPP;         // staging role: pixel inside a pass, 16-byte piece of its C channels
     const long img = (long)b * p.hi;
     const unsigned lds_g = (unsigned)(size_t)ts_smem + (unsigned)(g * 4 * ES);
+    // A thread's output pixels sit in two columns (psub, psub + 8) of the tile: the LDS addresses of the two source columns under each of the
+    // 2 x 3 (column, tap) positions and their horizontal weights do not change over the tile's rows or the three tap rows -- kept in registers
+    // (filled after the first barrier below, when colinfo is visible)
+    unsigned ca0[2][3], ca1[2][3];
+    float cw0[2][3], cw1[2][3];
     for (int dy = 0; dy < 3; ++dy) {
         // ---- stage the three taps (dy, 0..2) of the patch: LDS [tap][pixel][C] -------------------------------------------
         __syncthreads();     // the previous tap row has been consumed (and rowinfo / colinfo are written)
@@ -480,32 +485,42 @@ __global__ __launch_bounds__(256) void tapsum_resize_kernel(TapSumArgs p) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + t * C),
                                                  (__attribute__((address_space(3))) void*)(ts_smem + t * tapbytes + base * PIXB + wave * 1024), 16, 0, 0);
         }
+        if (dy == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const float4 ci = colinfo[h * 8 + psub + t];
+                    ca0[h][t] = lds_g + __builtin_bit_cast(unsigned, ci.x) + (unsigned)(t * tapbytes);
+                    ca1[h][t] = lds_g + __builtin_bit_cast(unsigned, ci.y) + (unsigned)(t * tapbytes);
+                    cw1[h][t] = ci.z * ci.w;                      // a fine column outside the image contributes nothing
+                    cw0[h][t] = (1.0f - ci.z) * ci.w;
+                }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (g < NG) {
 #pragma unroll
             for (int it = 0; it < TS_TH * TS_TW / 8; ++it) {
-                const int py = it >> 1, px = (it & 1) * 8 + psub;
+                const int py = it >> 1, h = it & 1;
                 const float4 ri = rowinfo[py + dy];
                 if (ri.w == 0.0f) continue;                       // fine row outside the image: zero padding (workgroup-uniform)
-                const unsigned r0 = lds_g + __builtin_bit_cast(unsigned, ri.x), r1 = lds_g + __builtin_bit_cast(unsigned, ri.y);
+                const unsigned r0 = __builtin_bit_cast(unsigned, ri.x), r1 = __builtin_bit_cast(unsigned, ri.y);
                 const float ly1 = ri.z, ly0 = 1.0f - ly1;
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    const float4 ci = colinfo[px + t];
-                    const unsigned c0 = __builtin_bit_cast(unsigned, ci.x) + (unsigned)(t * tapbytes), c1 = __builtin_bit_cast(unsigned, ci.y) + (unsigned)(t * tapbytes);
-                    const float lx1 = ci.z * ci.w, lx0 = (1.0f - ci.z) * ci.w;      // a fine column outside the image contributes nothing
-                    const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+                    const unsigned a00 = ca0[h][t] + r0, a01 = ca1[h][t] + r0, a10 = ca0[h][t] + r1, a11 = ca1[h][t] + r1;
+                    const float w00 = ly0 * cw0[h][t], w01 = ly0 * cw1[h][t], w10 = ly1 * cw0[h][t], w11 = ly1 * cw1[h][t];
                     if constexpr (ES == 2) {
-                        const u32x2 v00 = *(const __attribute__((address_space(3))) u32x2*)(size_t)(r0 + c0), v01 = *(const __attribute__((address_space(3))) u32x2*)(size_t)(r0 + c1);
-                        const u32x2 v10 = *(const __attribute__((address_space(3))) u32x2*)(size_t)(r1 + c0), v11 = *(const __attribute__((address_space(3))) u32x2*)(size_t)(r1 + c1);
+                        const u32x2 v00 = *(const __attribute__((address_space(3))) u32x2*)(size_t)a00, v01 = *(const __attribute__((address_space(3))) u32x2*)(size_t)a01;
+                        const u32x2 v10 = *(const __attribute__((address_space(3))) u32x2*)(size_t)a10, v11 = *(const __attribute__((address_space(3))) u32x2*)(size_t)a11;
                         fma_mix_lo(acc[it].x, w00, v00[0]); fma_mix_hi(acc[it].y, w00, v00[0]); fma_mix_lo(acc[it].z, w00, v00[1]); fma_mix_hi(acc[it].w, w00, v00[1]);
                         fma_mix_lo(acc[it].x, w01, v01[0]); fma_mix_hi(acc[it].y, w01, v01[0]); fma_mix_lo(acc[it].z, w01, v01[1]); fma_mix_hi(acc[it].w, w01, v01[1]);
                         fma_mix_lo(acc[it].x, w10, v10[0]); fma_mix_hi(acc[it].y, w10, v10[0]); fma_mix_lo(acc[it].z, w10, v10[1]); fma_mix_hi(acc[it].w, w10, v10[1]);
                         fma_mix_lo(acc[it].x, w11, v11[0]); fma_mix_hi(acc[it].y, w11, v11[0]); fma_mix_lo(acc[it].z, w11, v11[1]); fma_mix_hi(acc[it].w, w11, v11[1]);
                     } else {
-                        const f32x4 v00 = *(const __attribute__((address_space(3))) f32x4*)(size_t)(r0 + c0), v01 = *(const __attribute__((address_space(3))) f32x4*)(size_t)(r0 + c1);
-                        const f32x4 v10 = *(const __attribute__((address_space(3))) f32x4*)(size_t)(r1 + c0), v11 = *(const __attribute__((address_space(3))) f32x4*)(size_t)(r1 + c1);
+                        const f32x4 v00 = *(const __attribute__((address_space(3))) f32x4*)(size_t)a00, v01 = *(const __attribute__((address_space(3))) f32x4*)(size_t)a01;
+                        const f32x4 v10 = *(const __attribute__((address_space(3))) f32x4*)(size_t)a10, v11 = *(const __attribute__((address_space(3))) f32x4*)(size_t)a11;
                         acc[it].x += w00 * v00[0] + w01 * v01[0] + w10 * v10[0] + w11 * v11[0];
                         acc[it].y += w00 * v00[1] + w01 * v01[1] + w10 * v10[1] + w11 * v11[1];
                         acc[it].z += w00 * v00[2] + w01 * v01[2] + w10 * v10[2] + w11 * v11[2];

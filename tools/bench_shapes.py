@@ -36,7 +36,7 @@ def main():
         m(x, guide_mask=mask, observation=obs)  # warm-up, allocates the workspace
     # record every launch of one forward with its arguments, then replay each distinct one in isolation
     calls = []
-    real = {n: getattr(E, "k_" + n) for n in ("igemm", "attention", "layernorm", "patchify", "write_cls", "bilinear")}
+    real = {n: getattr(E, "k_" + n) for n in ("igemm", "attention", "layernorm", "patchify", "write_cls", "bilinear", "dpt_tail", "tapsum_resize")}
 
     def rec(name):
         def f(*a, **k):
@@ -58,7 +58,7 @@ def main():
         if name == "attention":
             return (name,) + tuple(a[2:])
         if name == "layernorm":
-            return (name, a[2], a[3], k.get("map_op", 0), k.get("out_f32") is not None)
+            return (name, a[2], a[3], k.get("map_op", 0), k.get("out_f32") is not None, k.get("out2_op") is not None, k.get("unshuffle_s", 0))
         if name == "bilinear":
             return (name,) + tuple(a[2:8]) + (k.get("add") is not None,)
         return (name,)
@@ -87,10 +87,14 @@ def main():
             flop = 4.0 * a[2] * a[4] * 64 * a[3] ** 2
             info.update(B=a[2], N=a[3], heads=a[4], tflops=flop / ms / 1e9)
         elif name == "layernorm":
-            byts = a[2] * a[3] * (4 + 2)
-            info.update(rows=a[2], dim=a[3], gbps=byts / ms / 1e6)
+            byts = a[2] * a[3] * (4 + 2) + (a[2] * a[3] * 2 if k.get("out2_op") is not None else 0)
+            info.update(rows=a[2], dim=a[3], gbps=byts / ms / 1e6, second_output=k.get("out2_op") is not None, unshuffle=k.get("unshuffle_s", 0))
         elif name == "bilinear":
             info.update(shape=list(a[2:8]))
+        elif name == "dpt_tail":
+            info.update(shape=list(a[2:8]), tflops=2.0 * a[2] * a[5] * a[6] * 32 * 9 * a[7] / ms / 1e9)
+        elif name == "tapsum_resize":
+            info.update(shape=list(a[2:8]), tap_map_dtype=str(a[0].dtype), gbps=(a[0].numel() * a[0].element_size() + a[2] * a[5] * a[6] * a[7] * 4) / ms / 1e6)
         rows.append(info)
     rows.sort(key=lambda r: -r["total_ms"])
     tot = sum(r["total_ms"] for r in rows)

@@ -233,3 +233,62 @@ def test_model_random_sizes_against_oracle(hip, case):
     err = rel_l1(out, ref)
     print(f"{kind} B={B} {H}x{W} {guide} {loss}: rel-L1 vs oracle = {err:.3e}")
     assert err <= 1e-3
+
+
+# ---- the single-precision head paths (sub-pixel merges, output_conv1 in front of its resize, fused tail) at odd sizes -------------------------
+# The ViT-S models above run their heads in split precision, which keeps the merged / commuted launches out of the path; ViT-B takes them
+# (default policy), and a raw model forced to head_precision="single" takes the raw-head merge (resize_layers + layer_rn, identity re-layout pass).
+SP_SIZES = [(14, 14), (14, 28), (28, 14), (42, 70), (126, 98), (70, 266), (182, 322), (266, 154)]
+
+
+@pytest.mark.parametrize("H,W", SP_SIZES, ids=lambda v: str(v))
+def test_vitb_single_precision_head_paths_at_odd_sizes(hip, H, W):
+    from _cases import build_product_model, case_inputs, oracle_forward, rel_l1, synth_state_dict
+    from hip_ext import engine as E
+    B = 2 if H * W < 40000 else 1
+    spec = dict(kind="amodal", encoder="vitb", guide_type="mask+observation", loss="entire_target_object", B=B, H=H, W=W, seed=70 + H + W)
+    model = build_product_model(spec)
+    sd = synth_state_dict(model)
+    x, grgb, mask, obs = case_inputs(spec)
+    tr = {}
+    oracle_forward(sd, spec, x, grgb, mask, obs, trace=tr)
+    key = "encoder.depth_head.scratch.output_conv2.2.bias"
+    sd[key] = sd[key] - float(tr["logits"].mean())
+    model.load_state_dict(sd, strict=True)
+    ref = oracle_forward(sd, spec, x, grgb, mask, obs)
+    model = model.cuda()
+    with torch.no_grad():
+        out = model(x.cuda(), guide_rgb=grgb.cuda(), guide_mask=mask.cuda(), observation=obs.cuda()).cpu()
+    w = model.encoder._engine().w
+    assert set(w.sp) == {0, 1} and w.oc1c is not None and E.SUBPIXEL and E.OC1_COMMUTE, "the merged / commuted launches were not on the path"
+    assert out.shape == ref.shape and torch.isfinite(out).all()
+    err = rel_l1(out, ref)
+    print(f"vitb amodal B={B} {H}x{W}: rel-L1 vs oracle = {err:.3e}")
+    assert err <= 1e-3
+
+
+@pytest.mark.parametrize("H,W", [(14, 14), (28, 42), (98, 154), (182, 126)], ids=lambda v: str(v))
+def test_raw_single_precision_head_merge_at_odd_sizes(hip, H, W):
+    """Geometry test of the raw-head sub-pixel merge: a raw ViT-S model forced to a single-precision head (its default is split, where the merge
+    does not apply).  The bar is 2e-3: a single-precision unbounded head sits around 1e-3 by itself -- a wrong ring, phase or
+    tap would show as 1e-1."""
+    from _cases import build_product_model, case_inputs, oracle_forward, rel_l1, synth_state_dict
+    spec = dict(kind="raw", encoder="vits", features=64, out_channels=[48, 96, 192, 384], B=2, H=H, W=W, seed=90 + H)
+    model = build_product_model(spec)
+    sd = synth_state_dict(model)
+    x, grgb, mask, obs = case_inputs(spec)
+    tr = {}
+    oracle_forward(sd, spec, x, grgb, mask, obs, trace=tr)
+    sd["depth_head.scratch.output_conv2.2.bias"] = sd["depth_head.scratch.output_conv2.2.bias"] - float(tr["logits"].mean()) + 1.5
+    model.load_state_dict(sd, strict=True)
+    ref = oracle_forward(sd, spec, x, grgb, mask, obs)
+    model.head_precision = "single"
+    model = model.cuda()
+    with torch.no_grad():
+        out = model(x.cuda()).cpu()
+    w = model._engine().w
+    assert set(w.sp) == {0, 1} and not w.amodal_head
+    assert out.shape == ref.shape and torch.isfinite(out).all()
+    err = rel_l1(out, ref)
+    print(f"raw vits single-precision head B=2 {H}x{W}: rel-L1 vs oracle = {err:.3e}")
+    assert err <= 2e-3

@@ -85,6 +85,8 @@ struct IgemmDev {
     int rowstat_groups;       // N / 64
     int split_seg;   // > 0: the op-typed output is written as [hi | lo] in two column segments of this width (split precision)
     int a_dup_seg;   // > 0: the A operand is a [hi | lo] split tensor contracted as (hi, lo, hi) against [w_hi | w_hi | w_lo] weights
+    int bias_row_mod;   // > 0: the bias vector depends on the row: row m uses bias[(m / bias_row_mod) * N + n] (one vector per group of rows)
+    FastDiv dBiasMod;
     int a_wrap;      // PLAIN, > 0: the A row is a_wrap elements long and the k-walk wraps around once: K = 2 * a_wrap against [w_hi | w_lo] weights
     int tap_cols;    // CONV3, > 0: the N columns come in blocks of tap_cols ("phases" of a sub-pixel convolution) that use only some of the 9 taps
     unsigned long long tap_bits[3];   // 9-bit tap masks of up to 16 blocks, seven per word
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 }
             }
         }
-    } else if (EPI != EPI_SHUFFLE && m0 + BM <= p.M && n0 + BN <= p.N && p.res_row_mod == 0 &&
+    } else if (EPI != EPI_SHUFFLE && m0 + BM <= p.M && n0 + BN <= p.N && p.res_row_mod == 0 && p.bias_row_mod == 0 &&
                (!p.out_op || p.map_op == ADA_MAP_PLAIN || (p.map_op == ADA_MAP_PAD && p.map_w >= 8)) &&
                (!p.out_f32 || p.map_f32 == ADA_MAP_PLAIN) &&
                (p.out_f32 || (flags & ADA_EP_RESIDUAL) || (p.ldo_op & 7) == 0)) {
@@ -827,6 +829,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                     const int m = mbase + i * 32 + row;
                     float4 v0 = *(const float4*)(slab + row * SW + 8 * cg);
                     float4 v1 = *(const float4*)(slab + row * SW + 8 * cg + 4);
+                    if (p.bias_row_mod > 0) {   // one bias vector per group of rows (the class-token read-out: a per-image bias, DA2/dpt.py:164-167)
+                        uint32_t grp, rr_;
+                        fast_divmod((uint32_t)(m < p.M ? m : p.M - 1), p.dBiasMod, grp, rr_);
+                        const float* brow = p.bias + (long)grp * p.N;
+                        b0 = nval ? *(const float4*)(brow + n) : make_float4(0, 0, 0, 0);
+                        b1 = nval2 ? *(const float4*)(brow + n + 4) : make_float4(0, 0, 0, 0);
+                    }
                     if (lnfold) {
                         const float2 st = *(const float2*)(p.ln_stats + (long)(m < p.M ? m : p.M - 1) * 2);
                         v0 = ln_fold4(v0, st.x, st.y, cs0, b0);
@@ -1194,6 +1203,11 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
         const int cols = shuffle ? a->shuffle_c : a->N;
         ADA_REQUIRE(cols <= a->split_seg && a->ldo_op >= 2L * a->split_seg, ADA_EINVAL, "ada_igemm: split_seg=%d too small for %d columns / ldo_op=%ld", a->split_seg, cols, (long)a->ldo_op);
     }
+    if (a->bias_row_mod != 0) {
+        ADA_REQUIRE(a->bias_row_mod > 0 && (f & ADA_EP_BIAS) && a->out_op && !a->out_f32 && !(f & (ADA_EP_RESIDUAL | ADA_EP_LNFOLD)) && !tail && !swiglu && !shuffle &&
+                    a->ldo_op % 8 == 0 && a->N % 4 == 0, ADA_EUNSUPPORTED,
+                    "ada_igemm: bias_row_mod (a bias vector per group of rows) is implemented for operand-typed outputs with ldo_op %% 8 == 0 (bias / GELU epilogues)");
+    }
     if (a->a_wrap != 0) {
         ADA_REQUIRE(a->a_mode == ADA_A_PLAIN && a->a_dup_seg == 0 && a->a_wrap > 0 && a->a_wrap % 64 == 0 && a->K == 2 * a->a_wrap && a->lda >= a->a_wrap, ADA_EINVAL,
                     "ada_igemm: a_wrap=%d needs a plain operand, K == 2 * a_wrap (K=%d) and lda >= a_wrap", a->a_wrap, a->K);
@@ -1230,6 +1244,8 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.split_seg = a->split_seg;
     d.a_dup_seg = a->a_dup_seg;
     d.a_wrap = a->a_wrap;
+    d.bias_row_mod = a->bias_row_mod;
+    d.dBiasMod = make_fastdiv(a->bias_row_mod > 0 ? a->bias_row_mod : 1);
     d.tap_cols = a->tap_cols;
     d.tap_bits[0] = d.tap_bits[1] = d.tap_bits[2] = 0;
     if (a->tap_cols > 0)

@@ -53,7 +53,7 @@ class IgemmArgs(ctypes.Structure):
         ("map_h", c_int32), ("map_w", c_int32), ("shuffle_s", c_int32), ("shuffle_c", c_int32),
         ("tail_w", c_void_p), ("tail_b", c_float), ("tail_act", c_int32),
         ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("rowstat_out", c_void_p), ("split_seg", c_int32), ("a_dup_seg", c_int32),
-        ("tap_cols", c_int32), ("tap_mask", c_uint16 * 16), ("a_wrap", c_int32),
+        ("tap_cols", c_int32), ("tap_mask", c_uint16 * 16), ("a_wrap", c_int32), ("bias_row_mod", c_int32),
     ]
 
 
@@ -223,7 +223,7 @@ def set_timer(t: Optional[KernelTimer]):
 def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=None, gamma=None, res=None, ldr=0,
           res_row_mod=0, res_row_off=0, flags=0, out_f32=None, ldo_f32=0, map_f32=MAP_PLAIN, out_op=None, ldo_op=0,
           map_op=MAP_PLAIN, map_h=0, map_w=0, shuffle_s=0, shuffle_c=0, tail_w=None, tail_b=0.0, tail_act=ACT_NONE, split_seg=0,
-          ln_stats=None, ln_colsum=None, rowstat_out=None, a_dup_seg=0, tap_cols=0, tap_mask=None, a_wrap=0):
+          ln_stats=None, ln_colsum=None, rowstat_out=None, a_dup_seg=0, tap_cols=0, tap_mask=None, a_wrap=0, bias_row_mod=0):
     op = operand_dtype()
     a = IgemmArgs()
     a.M, a.N, a.K, a.a_mode = M, N, K, a_mode
@@ -242,6 +242,7 @@ def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=Non
     a.split_seg = split_seg
     a.a_dup_seg = a_dup_seg
     a.a_wrap = a_wrap
+    a.bias_row_mod = bias_row_mod
     if tap_cols:
         a.tap_cols = tap_cols
         for i, m in enumerate(tap_mask):

@@ -746,9 +746,9 @@ class DepthEngine:
             Np = ph * pw
             for i in range(4):
                 k_igemm(M=B, N=D, k_alg=D, A=ws.cls_op[i], W=w.ro_wc[i], bias=w.ro_b[i], flags=EP_BIAS, out_f32=ws.cls_bias[i], ldo_f32=D, **self._kdup(KDr, w.ro_wc[i]))
-                for b in range(B):
-                    k_igemm(M=Np, N=D, k_alg=D, A=ws.taps[i][b * Np:(b + 1) * Np], W=w.ro_wx[i], bias=ws.cls_bias[i][b], **self._kdup(KDr, w.ro_wx[i]),
-                            flags=EP_BIAS | EP_GELU, out_op=ws.taps_ro[i][b * Np:(b + 1) * Np], ldo_op=ws.taps_ro[i].shape[1], split_seg=S("proj", D))
+                # one launch for the whole batch: the bias vector of row m is cls_bias[m // Np] (ada_igemm_args.bias_row_mod)
+                k_igemm(M=B * Np, N=D, k_alg=D, A=ws.taps[i], W=w.ro_wx[i], bias=ws.cls_bias[i], bias_row_mod=Np, **self._kdup(KDr, w.ro_wx[i]),
+                        flags=EP_BIAS | EP_GELU, out_op=ws.taps_ro[i], ldo_op=ws.taps_ro[i].shape[1], split_seg=S("proj", D))
             taps_in = ws.taps_ro
         # ---- reassemble: 1x1 project + resize (dpt.py:171-173) -> zero-bordered NHWC operand tensors -----
         KD = ws.taps[0].shape[1]

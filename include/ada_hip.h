@@ -149,6 +149,10 @@ typedef struct ada_igemm_args {
                                K = 2 * a_wrap with the A walk starting over at k = a_wrap, against weights packed [w_hi | w_lo] (w_hi = round(w),
                                w_lo = round(w - w_hi)):  x w_hi + x w_lo  -- the weight's rounding error is gone, the activation's stays
                                (used where the activation is produced in the operand type anyway: attention output, SwiGLU hidden).  0 = off */
+    int32_t bias_row_mod;   /* > 0: one bias vector per group of bias_row_mod consecutive rows: row m uses bias[(m / bias_row_mod) * N + n].  The
+                               use_clstoken read-out (DA2/dpt.py:110-117,164-167: Linear(2D, D) on [patch | class token] + GELU) is a D -> D GEMM over
+                               the patch tokens whose bias W_cls cls_b + b differs per image: one launch for the whole batch.  Operand-typed output
+                               only (bias / GELU epilogues).  0 = one bias vector [N] */
 } ada_igemm_args;
 
 int ada_igemm(const ada_igemm_args* args, void* stream);

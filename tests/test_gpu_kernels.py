@@ -264,6 +264,25 @@ def test_tapsum_resize_is_conv3x3_of_the_upsampled_map(hip, B, C, Cin, hi, wi, h
     assert err < (8e-3 if op == torch.bfloat16 else 1e-3)
 
 
+@pytest.mark.parametrize("G,rows,N,K,cfg,gelu", [(3, 50, 64, 128, -1, True), (5, 1369, 384, 384, -1, True), (2, 300, 256, 192, 3, False), (4, 77, 128, 64, 4, True), (7, 9, 96, 128, 1, False)])
+def test_igemm_bias_per_row_group(hip, forced_tile, G, rows, N, K, cfg, gelu):
+    """ada_igemm_args.bias_row_mod: one bias vector per group of rows (the class-token read-out's per-image bias) in ONE launch."""
+    op = _op(hip)
+    M = G * rows
+    x = _rand(M, K, seed=71).to(op).float()
+    w = (_rand(N, K, seed=72) * K ** -0.5).to(op).float()
+    b = _rand(G, N, seed=73)
+    out = torch.zeros(M, 2 * N, dtype=op, device=DEV)
+    if cfg >= 0:
+        forced_tile(cfg, 0)
+    hip.igemm(M=M, N=N, K=K, A=x.to(op).to(DEV), lda=K, W=w.to(op).to(DEV), bias=b.to(DEV), bias_row_mod=rows, flags=hip.EP_BIAS | (hip.EP_GELU if gelu else 0),
+              out_op=out, ldo_op=2 * N, split_seg=N)
+    ref = x @ w.T + b.repeat_interleave(rows, dim=0)
+    if gelu:
+        ref = F.gelu(ref)
+    _close(out[:, :N].float() + out[:, N:].float(), ref, 2e-5 if op == torch.float16 else 3e-4, rtol=2e-5 if op == torch.float16 else 3e-4, what="per-group bias (hi + lo)")
+
+
 def test_layernorm_second_output_drops_cls_rows(hip):
     """One pass, two normalised outputs of the same rows: all rows with (gain, bias) 1 -> the next block's LN1; the rows of every group of N
     but the first with (gain, bias) 2, compacted -> the tap LayerNorm (DA2/dinov2.py:337-340)."""

@@ -39,6 +39,12 @@ enum { EPI_STD = 0, EPI_GELU = 1, EPI_SHUFFLE = 2, EPI_SWIGLU = 3, EPI_TAIL = 4 
 #ifndef ADA_EPI_NT
 #define ADA_EPI_NT 4
 #endif
+#ifndef ADA_EPI_WT
+#define ADA_EPI_WT 0          // experiment: 1 = the fp32 residual-stream stores of the proj / fc2 epilogues are write-through (sc1) also without a LayerNorm tail
+#endif
+#ifndef ADA_LN_TAIL_PLAIN
+#define ADA_LN_TAIL_PLAIN 0   // experiment switch of the LayerNorm tail's reader: 1 = agent-scope acquire + plain loads, 0 = sc1 loads
+#endif
 ADA_DEV float4 ld_res4(const float* ptr) {
 #if ADA_EPI_NT & 1
     const f32x4 v = __builtin_nontemporal_load((const f32x4*)ptr);
@@ -46,6 +52,13 @@ ADA_DEV float4 ld_res4(const float* ptr) {
 #else
     return *(const float4*)ptr;
 #endif
+}
+// 16-byte fp32 store that is written through to memory (sc1): the form in which a tile publishes its rows to another workgroup of the SAME
+// launch (the LayerNorm tail below) -- cdna_hip_programming.md section 6, Guideline 16 R1 ("sc1 stores -> every wave s_waitcnt vmcnt(0) ->
+// __syncthreads() -> relaxed agent-scope ticket; the reader loads sc1").  A plain store would stay in this XCD's L2, invisible to a reader on another XCD.
+ADA_DEV void st_f32x4_wt(float* ptr, float4 v) {
+    const f32x4 t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(t) : "memory");
 }
 ADA_DEV void st_f32x4(float* ptr, float4 v) {
 #if ADA_EPI_NT & 2
@@ -85,6 +98,13 @@ struct IgemmDev {
     int rowstat_groups;       // N / 64
     int split_seg;   // > 0: the op-typed output is written as [hi | lo] in two column segments of this width (split precision)
     int a_dup_seg;   // > 0: the A operand is a [hi | lo] split tensor contracted as (hi, lo, hi) against [w_hi | w_hi | w_lo] weights
+    // LayerNorm tail: after the tiles of a row panel have written the fp32 output, the LAST of them to arrive normalises the panel's rows
+    const float* ln_weight;
+    const float* ln_bias;
+    float ln_eps;
+    op_t* ln_out;
+    long ld_ln;
+    unsigned* ln_counter;
     int bias_row_mod;   // > 0: the bias vector depends on the row: row m uses bias[(m / bias_row_mod) * N + n] (one vector per group of rows)
     FastDiv dBiasMod;
     int a_wrap;      // PLAIN, > 0: the A row is a_wrap elements long and the k-walk wraps around once: K = 2 * a_wrap against [w_hi | w_lo] weights
@@ -234,6 +254,20 @@ ADA_DEV void rowstat_store(const IgemmDev& p, float4 v, long row, int group, boo
         s2 += __shfl_xor(s2, o);
     }
     if (leader && valid) *(float2*)(p.rowstat_out + (row * p.rowstat_groups + group) * 2) = make_float2(s1, s2);
+}
+
+// Sum over the 64 lanes of a wave, result uniform: four DPP row rotations (sum over each 16-lane row in all of its lanes), then the four row
+// sums through SGPRs.  __shfl_xor is ds_bpermute on this part -- an LDS round trip per step, six dependent ones per reduction -- which is what
+// the LayerNorm tail below (two waves per SIMD, nobody to hide the latency behind) cannot afford.
+ADA_DEV float wave_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 #include "ada_igemm_pipe4.inc"
@@ -438,27 +472,31 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                         (unsigned)(a2o * 2), (unsigned)nk, period, cnt, jump);
     } else {
     // Offsets of the next slab to stage.  Plain operands walk k-step j directly; a 3x3 conv walks (active tap, k-step inside the tap) with two
-    // scalar counters (no division per k-step), the taps taken from taps_packed.
-    int w_j = 0, w_ti = 0, w_kc = 0;
-    auto next_offsets = [&](long& aoff, long& boff) {
+    // scalar counters (no division per k-step), the taps taken from taps_packed.  The walk state is passed and returned BY VALUE: captured by
+    // reference it has its address taken, and the "memory" clobbers of the loop's waits then pin it to scratch (12 bytes, reloaded every k-step).
+    struct Walk { int j, ti, kc; };
+    auto next_offsets = [=](Walk w, long& aoff, long& boff) -> Walk {
         if (p.a_mode == ADA_A_PLAIN) {
-            slab_offsets(w_j, aoff, boff);
-            ++w_j;
-            return;
+            aoff = (long)((wrap > 0 && w.j >= wrap) ? w.j - wrap : w.j) * BK;
+            boff = (long)w.j * BK;
+            w.j += 1;
+            return w;
         }
-        const int tap = (int)((taps_packed >> (4 * w_ti)) & 15ull);
-        const int kca = (sps > 0 && w_kc >= 2 * sps) ? w_kc - 2 * sps : w_kc;
+        const int tap = (int)((taps_packed >> (4 * w.ti)) & 15ull);
+        const int kca = (sps > 0 && w.kc >= 2 * sps) ? w.kc - 2 * sps : w.kc;
         const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
         aoff = ((long)dy * p.Wp + dx) * p.lda + (long)kca * BK;
-        boff = ((long)tap * cps + w_kc) * BK;
-        if (++w_kc == cps) {
-            w_kc = 0;
-            ++w_ti;
+        boff = ((long)tap * cps + w.kc) * BK;
+        if (++w.kc == cps) {
+            w.kc = 0;
+            ++w.ti;
         }
+        return w;
     };
+    Walk walk{0, 0, 0};
     {
         long aoff, boff;
-        next_offsets(aoff, boff);
+        walk = next_offsets(walk, aoff, boff);
         stage_part(0, aoff, boff, -1);
     }
     {
@@ -486,7 +524,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             const bool late = (NWAVES == 8) && wave < 4;
             const bool more = kt + 1 < nk;
             long aoff = 0, boff = 0;
-            if (more) next_offsets(aoff, boff);
+            if (more) walk = next_offsets(walk, aoff, boff);
             // (Spreading the 8 copies of a wave over the MFMAs of "its" k half -- two behind every 8 MFMAs, order pinned with sched_barrier, the
             // thing that was worth 20 % in the 4-wave loop -- makes THIS loop slower: fc1 +10 %, fc2 +14 %, 8192^3 +20 %; the partner wave on the
             // SIMD already covers a burst, and the pins cost the compiler its own schedule.  profiles/r03_i_gemm_4wave_asm_loop.txt)
@@ -766,7 +804,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                             w.x = __builtin_fmaxf(w.x, 0.f); w.y = __builtin_fmaxf(w.y, 0.f);
                             w.z = __builtin_fmaxf(w.z, 0.f); w.w = __builtin_fmaxf(w.w, 0.f);
                         }
-                        st_f32x4(p.out_f32 + (mrow + k * RPI) * ldf + n, w);
+                        if (p.ln_out || (ADA_EPI_WT && has_res)) st_f32x4_wt(p.out_f32 + (mrow + k * RPI) * ldf + n, w);
+                        else st_f32x4(p.out_f32 + (mrow + k * RPI) * ldf + n, w);
                     }
                     if (p.out_op) {
                         if (relu_o) {
@@ -957,7 +996,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                             w.x = __builtin_fmaxf(w.x, 0.f); w.y = __builtin_fmaxf(w.y, 0.f);
                             w.z = __builtin_fmaxf(w.z, 0.f); w.w = __builtin_fmaxf(w.w, 0.f);
                         }
-                        *(float4*)(p.out_f32 + frow * p.ldo_f32 + n) = w;
+                        if (p.ln_out) st_f32x4_wt(p.out_f32 + frow * p.ldo_f32 + n, w);
+                        else *(float4*)(p.out_f32 + frow * p.ldo_f32 + n) = w;
                     }
                     if (p.out_op) {
                         if (flags & ADA_EP_RELU_OP) {
@@ -986,6 +1026,97 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                     for (int k = 0; k < NKI; ++k) rcur[k] = rnext[k];
                 }
             }
+        }
+    }
+    // ---- LayerNorm tail (ada_igemm_args.ln_out): the LayerNorm that follows proj / fc2 (reference block.py:84,87) reads exactly the rows this
+    //      launch has just written to the fp32 residual stream.  Every tile publishes its part of the row panel (write-through stores above, the
+    //      wave's stores drained, one ticket per tile on the panel's counter); the tile that draws the last ticket normalises the panel's rows
+    //      from memory and writes the operand-typed LayerNorm output -- no separate launch, no second pass of all CUs over the stream.
+    //      Protocol: cdna_hip_programming.md section 6 Guideline 16 (R1: sc1 stores, vmcnt(0), __syncthreads(), relaxed agent-scope fetch_add;
+    //      reader: sc1 loads) -- correct for any placement of a panel's tiles over CUs / XCDs.  The result does not depend on which tile is last.
+    //      Built into the 256x256 tile's standard-epilogue kernel only (the tail keeps 8 rows x 6 chunks per lane in flight: 192 registers, which the
+    //      co-resident small tiles cannot spare); ada_igemm pins that tile when ln_out is set.
+    constexpr bool HAS_LN_TAIL = BM == 256 && BN == 256 && NWAVES == 8 && EPI == EPI_STD && !PIPE4;
+    if (HAS_LN_TAIL && p.ln_out) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through stores have reached memory
+        __syncthreads();
+        unsigned* const ticket = (unsigned*)smem;            // the stage buffers / epilogue slabs are dead
+        if (tid == 0) *ticket = __hip_atomic_fetch_add(p.ln_counter + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned drawn = *(volatile unsigned*)ticket;
+        if (drawn == (unsigned)p.tiles_n - 1u) {
+            if (tid == 0) __hip_atomic_store(p.ln_counter + tm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+#if ADA_LN_TAIL_PLAIN
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // experiment: acquire + plain loads instead of sc1 loads
+            __syncthreads();
+#endif
+            const int nchunk = p.N >> 2;                     // float4 chunks per row (N % 4 == 0; N <= 1536)
+            const int rows = (p.M - m0) < BM ? (p.M - m0) : BM;
+            // a buffer resource over the panel: sc1 loads (L1 bypassed; nobody on this XCD has read these lines during the launch) with compiler-managed waits
+            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_f32 + (long)m0 * p.ldo_f32), 0, 0x7fffffff, 0x20000);
+            const float inv_n = 1.0f / (float)p.N;
+            // A wave owns BM / NWAVES consecutive rows and takes them RB at a time: all loads of a batch are in flight together, the LayerNorm gain /
+            // bias of the lane's columns stay in registers, the reductions run on DPP.  (Row by row with shuffle reductions the panel took ~140 us --
+            // 32 dependent memory round trips and ~400 LDS round trips per wave with one partner wave to hide them behind; profiles/r04_j_*.)
+            constexpr int RPW = BM / NWAVES;
+            auto ln_rows = [&](auto ch_, auto rb_) {
+                constexpr int CH = decltype(ch_)::value, RB = decltype(rb_)::value;
+                static_assert(RPW % RB == 0, "rows per wave vs batch");
+                float4 gw[CH], gb[CH];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int c = lane + 64 * i;
+                    gw[i] = gb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c < nchunk) { gw[i] = *(const float4*)(p.ln_weight + 4 * c); gb[i] = *(const float4*)(p.ln_bias + 4 * c); }
+                }
+                for (int r0 = wave * RPW; r0 < wave * RPW + RPW && r0 < rows; r0 += RB) {
+                    f32x4 v[RB][CH];
+#pragma unroll
+                    for (int j = 0; j < RB; ++j) {
+                        const int r = r0 + j < rows ? r0 + j : rows - 1;
+#pragma unroll
+                        for (int i = 0; i < CH; ++i) {
+                            const int c = lane + 64 * i;
+                            v[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (c < nchunk)
+                                v[j][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(((long)r * p.ldo_f32 + 4 * c) * 4), 0, ADA_LN_TAIL_PLAIN ? 0 : 16));
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < RB; ++j) {
+                        float s1 = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < CH; ++i) s1 += (v[j][i][0] + v[j][i][1]) + (v[j][i][2] + v[j][i][3]);     // chunks past the row are zero
+                        const float mean = wave_sum_dpp(s1) * inv_n;
+                        float s2 = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < CH; ++i) {
+                            if (lane + 64 * i < nchunk) {
+                                const float a = v[j][i][0] - mean, b = v[j][i][1] - mean, c2 = v[j][i][2] - mean, d = v[j][i][3] - mean;
+                                s2 += (a * a + b * b) + (c2 * c2 + d * d);
+                            }
+                        }
+                        const float rstd = 1.0f / sqrtf(wave_sum_dpp(s2) * inv_n + p.ln_eps);
+                        if (r0 + j < rows) {
+                            op_t* const yrow = p.ln_out + (long)(m0 + r0 + j) * p.ld_ln;
+#pragma unroll
+                            for (int i = 0; i < CH; ++i) {
+                                const int c = lane + 64 * i;
+                                if (c < nchunk) {
+                                    float4 y;
+                                    y.x = (v[j][i][0] - mean) * rstd * gw[i].x + gb[i].x;
+                                    y.y = (v[j][i][1] - mean) * rstd * gw[i].y + gb[i].y;
+                                    y.z = (v[j][i][2] - mean) * rstd * gw[i].z + gb[i].z;
+                                    y.w = (v[j][i][3] - mean) * rstd * gw[i].w + gb[i].w;
+                                    *(opx4*)(yrow + 4 * c) = pack4(y);
+                                }
+                            }
+                        }
+                    }
+                }
+            };
+            if (nchunk <= 256) ln_rows(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});     // N <= 1024
+            else ln_rows(std::integral_constant<int, 6>{}, std::integral_constant<int, 4>{});                   // N <= 1536
         }
     }
     if (!PIPE4 && p.dbg && tid == 0) {
@@ -1055,7 +1186,7 @@ static inline double tile_time(long M, long N, int bm, int bn, int occ, double e
 // main loop of the 256x256 tile: variant 16 forces the hand-scheduled 4-wave loop, 4 the single-barrier 8-wave loop; 0 (default) picks the
 // 4-wave loop where its main loop outweighs its slower prologue / epilogue (measured: k-loops of >= 128 k-tiles)
 // (its scalar A-offset counters assume a monotonic walk: a split operand, whose third k segment re-reads the first, stays on the 8-wave loop)
-static inline bool use_pipe4(const IgemmDev& d) { return d.a_dup_seg == 0 && d.a_wrap == 0 && d.tap_cols == 0 && (d.variant >= 16 || (d.variant == 0 && d.K >= 8192)); }
+static inline bool use_pipe4(const IgemmDev& d) { return d.a_dup_seg == 0 && d.a_wrap == 0 && d.tap_cols == 0 && d.ln_out == nullptr && (d.variant >= 16 || (d.variant == 0 && d.K >= 8192)); }
 
 template <int EPI>
 int launch_epi(IgemmDev& d, hipStream_t s, int force) {
@@ -1078,6 +1209,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force) {
     }
     if (d.M < 256 && cfg >= 2 && cfg != 4) cfg = 4;
     if (force >= 0 && force <= 4) cfg = force;
+    if (d.ln_out) cfg = 3;     // the LayerNorm tail lives in the 256x256 tile's kernel
     // EP_ROWSTATS reduces a row over the 16 lanes that hold one 64-column group: the 32-column-wide 256x32 tile has no such group
     if ((d.flags & ADA_EP_ROWSTATS) && cfg == 0) cfg = 1;
     if constexpr (EPI == EPI_SWIGLU) {
@@ -1203,6 +1335,13 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
         const int cols = shuffle ? a->shuffle_c : a->N;
         ADA_REQUIRE(cols <= a->split_seg && a->ldo_op >= 2L * a->split_seg, ADA_EINVAL, "ada_igemm: split_seg=%d too small for %d columns / ldo_op=%ld", a->split_seg, cols, (long)a->ldo_op);
     }
+    if (a->ln_out) {
+        ADA_REQUIRE(a->ln_weight && a->ln_bias && a->ln_counter && a->out_f32 && a->map_f32 == ADA_MAP_PLAIN && a->res_row_mod == 0 && !tail && !swiglu && !shuffle &&
+                    a->N <= 1536 && a->N % 4 == 0 && a->ldo_f32 % 4 == 0 && a->ld_ln % 4 == 0 && ((uintptr_t)a->ln_out % 8) == 0 &&
+                    ((uintptr_t)a->ln_weight % 16) == 0 && ((uintptr_t)a->ln_bias % 16) == 0, ADA_EUNSUPPORTED,
+                    "ada_igemm: the LayerNorm tail needs a plain fp32 output whose N (<= 1536) is the whole LayerNorm row, ln_weight / ln_bias / ln_counter, 8-byte aligned ln_out");
+        ADA_REQUIRE(!(f & (ADA_EP_GELU | ADA_EP_ROWSTATS | ADA_EP_LNFOLD)), ADA_EUNSUPPORTED, "ada_igemm: the LayerNorm tail is built for the standard (bias / LayerScale / residual) epilogue");
+    }
     if (a->bias_row_mod != 0) {
         ADA_REQUIRE(a->bias_row_mod > 0 && (f & ADA_EP_BIAS) && a->out_op && !a->out_f32 && !(f & (ADA_EP_RESIDUAL | ADA_EP_LNFOLD)) && !tail && !swiglu && !shuffle &&
                     a->ldo_op % 8 == 0 && a->N % 4 == 0, ADA_EUNSUPPORTED,
@@ -1244,6 +1383,8 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.split_seg = a->split_seg;
     d.a_dup_seg = a->a_dup_seg;
     d.a_wrap = a->a_wrap;
+    d.ln_weight = a->ln_weight; d.ln_bias = a->ln_bias; d.ln_eps = a->ln_eps; d.ln_out = (op_t*)a->ln_out; d.ld_ln = a->ld_ln;
+    d.ln_counter = (unsigned*)a->ln_counter;
     d.bias_row_mod = a->bias_row_mod;
     d.dBiasMod = make_fastdiv(a->bias_row_mod > 0 ? a->bias_row_mod : 1);
     d.tap_cols = a->tap_cols;

@@ -28,7 +28,9 @@ ARCH = "gfx950"
 # (-Wno-inline-asm: the generated loop lists m0 among its clobbers -- it rewrites m0 for its LDS-DMA copies and the backend's merging of
 # identical m0 initialisations must see that -- and clang warns about every reserved register in a clobber list.)
 PER_FILE_FLAGS = {"ada_tail.hip": ["-fno-slp-vectorize"], "ada_igemm.hip": ["-fno-slp-vectorize", "-Wno-inline-asm"]}
-NO_SCRATCH = {"ada_tail.hip"}
+# ada_igemm.hip joined in round 4: a by-reference lambda capture of the k-walk counters put them into scratch behind the loop's "memory"-clobbering
+# waits -- 12 bytes reloaded every k-step of every GEMM, silently, for most of a round.  No kernel of these files may use scratch or spill VGPRs.
+NO_SCRATCH = {"ada_tail.hip", "ada_igemm.hip"}
 # Round 4: the wrong results above were root-caused (profiles/r04_a_tail_inflight_register_root_cause.txt) -- NOT a hardware hazard of packed
 # fp32 beside MFMAs (tools/ubench/pk_f32_beside_mfma.hip: 0 mismatches) but the compiler copying registers that the kernel's inline-asm
 # fetches were still writing: with SLP on, the allocator parks a source row in other registers with v_mov_b64 placed ABOVE the hand-counted

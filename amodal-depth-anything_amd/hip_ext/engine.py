@@ -84,6 +84,10 @@ SUBPIXEL = os.environ.get("ADA_SUBPIXEL", "1") == "1"
 # -- ONE GEMM over the 148^2 grid with N = 9 * features / 2 (0.41 TFLOP at ViT-L bs = 32 instead of out_conv 0.09 + output_conv1 1.65) whose nine
 # operand-typed tap maps ada_tapsum_resize_fwd gathers (9 taps x 4 bilinear corners per output element; a tap whose position falls into the
 # zero padding drops out whole, out_conv's bias included).  The up-sampled operand map p1 is never written.  ADA_OC1_COMMUTE=0: the old path.
+# LayerNorm tail (round 4, ada_igemm_args.ln_out): norm2 behind attn.proj and the next block's norm1 behind mlp.fc2 (block.py:84,87) are computed by
+# the proj / fc2 launch itself -- the last-arriving tile of every 256-row panel normalises the panel it has just completed -- instead of by a
+# separate pass of all CUs over the fp32 residual stream.  ADA_LN_TAIL=0: separate ada_layernorm launches.
+LN_TAIL = os.environ.get("ADA_LN_TAIL", "0") == "1"
 OC1_COMMUTE = int(os.environ.get("ADA_OC1_COMMUTE", "16"))     # 0: off; 16: operand-typed tap maps (default); 32: fp32 tap maps (no parity gain, slower)
 
 
@@ -408,6 +412,7 @@ class Workspace:
         if pw_.fold_ln:
             self.part = z(T, D // 64, 2, dtype=torch.float32)    # per-row partial (sum, sum of squares), one slot per 64 columns
             self.stats = z(T, 2, dtype=torch.float32)            # (mean, rstd) per row
+        self.ln_cnt = torch.zeros(T // 128 + 2, dtype=torch.int32, device=device)     # per-row-panel tickets of the LayerNorm tail (kernel-reset)
         self.qkv = z(T, 3 * D)
         self.o = z(T, D)
         hidden = pw_.blocks[0]["hidden"]
@@ -596,7 +601,7 @@ class DepthEngine:
         if not use or instrumented() or torch.cuda.is_current_stream_capturing():
             return self._forward(x, guide, norm)
         # the kernel variant / tile override / fused-tail switch in force at capture time are baked into the graph
-        key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device), debug_epoch(), FUSED_TAIL, SUBPIXEL, OC1_COMMUTE, norm)
+        key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device), debug_epoch(), FUSED_TAIL, SUBPIXEL, OC1_COMMUTE, LN_TAIL, norm)
         with self._lock:
             g = self._graphs.get(key)
             if g is not None:
@@ -664,6 +669,11 @@ class DepthEngine:
 
         def seg(blk_):              # split_seg of the LayerNorm that feeds blk_'s linear layers
             return D if blk_["esplit"] else 0
+        def lntail(blk_, wk, bk):   # LayerNorm-tail arguments of a proj / fc2 launch whose output rows feed LayerNorm (blk_[wk], blk_[bk]) -> ws.y
+            # (the tail lives in the 256x256 tile's kernel: only where the tile heuristic takes that tile anyway -- at least a full round of tiles)
+            if not LN_TAIL or blk_["esplit"] or D > 1536 or T < 16384:
+                return {}
+            return dict(ln_weight=blk_[wk], ln_bias=blk_[bk], ln_eps=LN_EPS, ln_out=ws.y, ld_ln=ldy, ln_counter=ws.ln_cnt)
         ln1_done = False    # block i's norm1 output already sits in ws.y (emitted by the tap LayerNorm of block i - 1, see below)
         for i, blk in enumerate(w.blocks):
             last = i == len(w.blocks) - 1
@@ -692,19 +702,25 @@ class DepthEngine:
                             flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL | EP_ROWSTATS, out_f32=ws.x, ldo_f32=D, out_op=ws.y, ldo_op=D, rowstat_out=ws.part)
                     k_rowstats_finalize(ws.part, T, G, LN_EPS, ws.stats)
             else:
+                tail2 = lntail(blk, "ln2_w", "ln2_b")
                 k_igemm(M=T, N=D, k_alg=D, A=ws.o, W=blk["proj_w"], bias=blk["proj_b"], gamma=blk["ls1"], res=ws.x, ldr=D,
-                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, D))
-                k_layernorm(ws.x, D, T, D, blk["ln2_w"], blk["ln2_b"], LN_EPS, out_op=ws.y, ld_op=ldy, split_seg=seg(blk))
+                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, D), **tail2)
+                if not tail2:
+                    k_layernorm(ws.x, D, T, D, blk["ln2_w"], blk["ln2_b"], LN_EPS, out_op=ws.y, ld_op=ldy, split_seg=seg(blk))
+                # the next block's norm1 rides on this block's fc2 / w3 -- unless this is a tap block (its tap LayerNorm emits norm1 as a second output)
+                tail1 = {} if (last or i in taps) else lntail(w.blocks[i + 1], "ln1_w", "ln1_b")
+                if tail1:
+                    ln1_done = True
                 if w.ffn == "mlp":
                     k_igemm(M=T, N=hid, k_alg=D, A=ws.y, W=blk["fc1_w"], bias=blk["fc1_b"], flags=EP_BIAS | EP_GELU,
                             out_op=ws.hd, ldo_op=hid, **a_ln(blk, "fc1_w"))
                     k_igemm(M=T, N=D, k_alg=hid, A=ws.hd, W=blk["fc2_w"], bias=blk["fc2_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
-                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, hid))
+                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, hid), **tail1)
                 else:
                     k_igemm(M=T, N=2 * hid, k_alg=D, A=ws.y, W=blk["w12_w"], bias=blk["w12_b"], flags=EP_BIAS | EP_SWIGLU,
                             out_op=ws.hd, ldo_op=hid, **a_ln(blk, "w12_w"))
                     k_igemm(M=T, N=D, k_alg=hid, A=ws.hd, W=blk["w3_w"], bias=blk["w3_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
-                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, hid))
+                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, hid), **tail1)
             if i in taps:  # shared final LayerNorm on the tap, cls row dropped (dinov2.py:337-340)
                 tap = ws.taps[taps.index(i)]
                 if not last and not fold:

@@ -153,6 +153,17 @@ typedef struct ada_igemm_args {
                                use_clstoken read-out (DA2/dpt.py:110-117,164-167: Linear(2D, D) on [patch | class token] + GELU) is a D -> D GEMM over
                                the patch tokens whose bias W_cls cls_b + b differs per image: one launch for the whole batch.  Operand-typed output
                                only (bias / GELU epilogues).  0 = one bias vector [N] */
+    /* LayerNorm tail (ln_out != NULL): the LayerNorm that follows the contraction -- norm2 behind attn.proj, the next block's norm1 behind mlp.fc2
+       (DA2/dinov2_layers/block.py:84,87) -- reads the rows this launch writes to out_f32.  With N = the whole LayerNorm row, the last of a row
+       panel's tiles to finish normalises the panel (biased variance, eps inside the sqrt) and writes ln_out[m, :N] operand-typed: no separate
+       ada_layernorm_fwd launch.  ln_counter: device uint32[ceil(M / 128)], zero before the first use; the kernel returns it to zero.
+       Inter-workgroup protocol: write-through stores, drained, one agent-scope ticket per tile; the reader loads sc1. */
+    const float* ln_weight;
+    const float* ln_bias;
+    float ln_eps;
+    void* ln_out;
+    int64_t ld_ln;
+    void* ln_counter;
 } ada_igemm_args;
 
 int ada_igemm(const ada_igemm_args* args, void* stream);

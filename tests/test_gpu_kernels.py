@@ -283,6 +283,48 @@ def test_igemm_bias_per_row_group(hip, forced_tile, G, rows, N, K, cfg, gelu):
     _close(out[:, :N].float() + out[:, N:].float(), ref, 2e-5 if op == torch.float16 else 3e-4, rtol=2e-5 if op == torch.float16 else 3e-4, what="per-group bias (hi + lo)")
 
 
+@pytest.mark.parametrize("M,N,K,cfg", [(4110, 1024, 256, -1), (4110, 1024, 256, 3), (2740, 768, 128, 4), (1370, 384, 192, 1), (700, 1536, 64, 2), (5000, 1024, 1024, 3), (257, 256, 64, -1)])
+def test_igemm_layernorm_tail(hip, forced_tile, M, N, K, cfg):
+    """ada_igemm_args.ln_out: the last-arriving tile of each row panel normalises the rows the launch has just written (inter-workgroup hand-off inside
+    one launch: write-through stores, drained, one agent-scope ticket per tile, sc1 loads on the reader).  Every word of the LayerNorm output is checked
+    against the stand-alone kernel on the same fp32 rows, 12 launches per shape with a second stream loading the memory system on every other one
+    (uneven load is what exposes a missing release / acquire), and the tickets must be back at zero after every launch."""
+    op = _op(hip)
+    A = _rand(M, K, seed=81).to(op).to(DEV)
+    W = (_rand(N, K, seed=82) * K ** -0.5).to(op).to(DEV)
+    b, g = _rand(N, seed=83).to(DEV), (0.3 + 0.7 * torch.rand(N, generator=torch.Generator().manual_seed(84))).to(DEV)
+    lw, lb = (1.0 + 0.1 * _rand(N, seed=85)).to(DEV), (0.1 * _rand(N, seed=86)).to(DEV)
+    cnt = torch.zeros(M // 128 + 2, dtype=torch.int32, device=DEV)
+    side = torch.cuda.Stream()
+    noise = torch.randn(1 << 25, device=DEV)
+    if cfg >= 0:
+        forced_tile(cfg, 0)
+    for rep in range(12):
+        x0 = _rand(M, N, seed=90 + rep).to(DEV)
+        x_ref, x_tail = x0.clone(), x0.clone()
+        y_tail = torch.full((M, N), float("nan"), dtype=op, device=DEV)
+        kw = dict(M=M, N=N, K=K, A=A, lda=K, W=W, bias=b, gamma=g, ldr=N, flags=hip.EP_BIAS | hip.EP_GAMMA | hip.EP_RESIDUAL, ldo_f32=N)
+        hip.igemm(res=x_ref, out_f32=x_ref, **kw)
+        y_ref = torch.empty(M, N, dtype=op, device=DEV)
+        hip.layernorm(x_ref, N, M, N, lw, lb, 1e-6, out_op=y_ref, ld_op=N)
+        if rep & 1:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    noise.mul_(1.0001)
+        hip.igemm(res=x_tail, out_f32=x_tail, ln_weight=lw, ln_bias=lb, ln_eps=1e-6, ln_out=y_tail, ld_ln=N, ln_counter=cnt, **kw)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(x_tail, x_ref), f"rep {rep}: the fp32 rows differ from the launch without the tail"
+        assert int(cnt.abs().sum()) == 0, f"rep {rep}: tickets not returned to zero"
+        d = (y_tail.float() - y_ref.float()).abs()
+        assert torch.isfinite(y_tail.float()).all(), f"rep {rep}: {int((~torch.isfinite(y_tail.float())).sum())} rows never normalised"
+        # same rows, same formula; the mean is s * (1 / N) here and s / N there: at most one operand ulp apart
+        bad = d > 2e-3 * y_ref.float().abs() + 2e-3
+        assert not bad.any(), f"rep {rep}: {int(bad.sum())} of {bad.numel()} LayerNorm outputs differ (max {float(d.max()):.3e}) -- stale rows?"
+    ref = F.layer_norm(x_ref.cpu(), (N,), lw.cpu(), lb.cpu(), 1e-6)
+    _close(y_tail, ref, 4e-3 if op == torch.float16 else 3e-2, rtol=4e-3 if op == torch.float16 else 2e-2, what="LayerNorm tail vs torch")
+
+
 def test_layernorm_second_output_drops_cls_rows(hip):
     """One pass, two normalised outputs of the same rows: all rows with (gain, bias) 1 -> the next block's LN1; the rows of every group of N
     but the first with (gain, bias) 2, compacted -> the tap LayerNorm (DA2/dinov2.py:337-340)."""

@@ -2,6 +2,7 @@
 inputs.  Shapes are drawn so that every edge the kernels have is hit many times: single rows, ragged last tiles in M and N, N not a multiple of
 the tile width, lda / ldo larger than the logical width, odd numbers of k-tiles, forced and heuristic tile choices, every epilogue of the
 linear-layer path.  Output buffers carry guard columns / rows that must come back untouched (no out-of-bounds store)."""
+import os
 import random
 
 import pytest
@@ -11,6 +12,10 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 GUARD = 1024.0      # exactly representable in fp16 and bf16
+# One-off extended sweeps (profiles/r0N_*_extended_fuzz.txt): ADA_FUZZ_SCALE multiplies the number of cases of every family, ADA_FUZZ_SEED is
+# added to every family's seed.  Unset (the suite, the driver): the fixed cases below.
+FUZZ_SCALE = max(1, int(os.environ.get("ADA_FUZZ_SCALE", "1")))
+FUZZ_SEED = int(os.environ.get("ADA_FUZZ_SEED", "0"))
 LOG2E = 1.4426950408889634
 
 
@@ -44,7 +49,7 @@ def _asm_loop_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(72, 20261002) + _asm_loop_cases(24, 31337), ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}x{c[3]}-{c[4]}-t{c[5]}")
+@pytest.mark.parametrize("case", _cases(72 * FUZZ_SCALE, 20261002 + FUZZ_SEED) + _asm_loop_cases(24 * FUZZ_SCALE, 31337 + FUZZ_SEED), ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}x{c[3]}-{c[4]}-t{c[5]}")
 def test_igemm_random_shapes(hip, case):
     i, M, N, K, epi, tile, pad_a, pad_o = case
     op = hip.operand_dtype()
@@ -105,7 +110,7 @@ def _attn_cases(n, seed):
              rng.choice([5, 3])) for i in range(n)]
 
 
-@pytest.mark.parametrize("case", _attn_cases(36, 77), ids=lambda c: f"{c[0]}-B{c[1]}-N{c[2]}-h{c[3]}-v{c[4]}")
+@pytest.mark.parametrize("case", _attn_cases(36 * FUZZ_SCALE, 77 + FUZZ_SEED), ids=lambda c: f"{c[0]}-B{c[1]}-N{c[2]}-h{c[3]}-v{c[4]}")
 def test_attention_random_shapes(hip, case):
     i, B, N, heads, variant = case
     op = hip.operand_dtype()
@@ -143,7 +148,7 @@ def _head_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _head_cases(63, 4242), ids=lambda c: f"{c[0]}-{c[1]}-B{c[2]}-{c[3]}x{c[4]}-C{c[5]}-Co{c[6]}")
+@pytest.mark.parametrize("case", _head_cases(63 * FUZZ_SCALE, 4242 + FUZZ_SEED), ids=lambda c: f"{c[0]}-{c[1]}-B{c[2]}-{c[3]}x{c[4]}-C{c[5]}-Co{c[6]}")
 def test_head_operators_random_geometry(hip, case):
     from hip_ext import functional as HF
     i, kind, B, H, W, C, Co, size = case
@@ -203,7 +208,7 @@ def _model_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _model_cases(12, 99), ids=lambda c: f"{c[0]}-{c[1]}-B{c[2]}-{c[3]}x{c[4]}-{c[5]}-{c[6][:3]}")
+@pytest.mark.parametrize("case", _model_cases(12 * FUZZ_SCALE, 99 + FUZZ_SEED), ids=lambda c: f"{c[0]}-{c[1]}-B{c[2]}-{c[3]}x{c[4]}-{c[5]}-{c[6][:3]}")
 def test_model_random_sizes_against_oracle(hip, case):
     """Non-square inputs from one patch to 336 x 420: bicubic position tables for many grids, head grids down to 1 x 1, every guide type, both
     head activations, the raw model -- HIP path vs the fp32 oracle on the same synthetic weights, the one 1e-3 bar."""
@@ -239,6 +244,9 @@ def test_model_random_sizes_against_oracle(hip, case):
 # The ViT-S models above run their heads in split precision, which keeps the merged / commuted launches out of the path; ViT-B takes them
 # (default policy), and a raw model forced to head_precision="single" takes the raw-head merge (resize_layers + layer_rn, identity re-layout pass).
 SP_SIZES = [(14, 14), (14, 28), (28, 14), (42, 70), (126, 98), (70, 266), (182, 322), (266, 154)]
+if FUZZ_SCALE > 1:
+    _rng = random.Random(5150 + FUZZ_SEED)
+    SP_SIZES = sorted(set(SP_SIZES) | {(14 * _rng.randint(1, 24), 14 * _rng.randint(1, 24)) for _ in range(6 * FUZZ_SCALE)})
 
 
 @pytest.mark.parametrize("H,W", SP_SIZES, ids=lambda v: str(v))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Board power and shader clock WHILE one kernel loops: each of the ViT-L bs=32 GEMM shapes and the attention kernel is launched back to back for
 --seconds, and `rocm-smi --showpower --showclocks` is sampled once a second from a helper thread during the loop (not after it).
-    python tools/power_loops.py [--seconds 12]"""
+    python tools/power_loops.py [--seconds 12] [--forward]      (--forward: the whole ViT-L bs=32 forward of bench.py instead of single kernels)"""
 import argparse
 import os
 import re
@@ -30,7 +30,7 @@ def sample(stop, rows):
         stop.wait(1.0)
 
 
-def loop(name, fn, flop, seconds):
+def loop(name, fn, flop, seconds, chunk=200):
     fn()
     torch.cuda.synchronize()
     stop, rows = threading.Event(), []
@@ -39,10 +39,10 @@ def loop(name, fn, flop, seconds):
     th.start()
     n = 0
     while time.time() - t0 < seconds:
-        for _ in range(200):
+        for _ in range(chunk):
             fn()
         torch.cuda.synchronize()
-        n += 200
+        n += chunk
     dt = time.time() - t0
     stop.set()
     th.join()
@@ -56,7 +56,23 @@ def loop(name, fn, flop, seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=12.0)
+    ap.add_argument("--forward", action="store_true")
     a = ap.parse_args()
+    if a.forward:
+        from src.models import get_model
+        from src.util.synth_weights import fill_state_dict_, make_inputs
+        m = get_model("AmodalDAv2", guide_type="mask+observation", loss_stategy="entire_target_object", encoder="vitl", pretrained=False).eval()
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        fill_state_dict_(sd, 0)
+        m.load_state_dict(sd)
+        m = m.cuda()
+        x, _, mask, obs = make_inputs(32, 518, 518, 100, device="cuda")
+
+        def fwd():
+            with torch.no_grad():
+                m(x, guide_rgb=None, guide_mask=mask, observation=obs)
+        loop("AmodalDAv2 ViT-L 32 x 518^2", fwd, 32 * 1389.65e9, a.seconds, chunk=10)
+        return
     op = H.operand_dtype()
     dev = "cuda"
     torch.manual_seed(0)

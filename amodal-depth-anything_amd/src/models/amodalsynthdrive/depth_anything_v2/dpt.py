@@ -161,6 +161,7 @@ def _head_split_policy(mode, encoder, final_act):
 # depending on the weight draw (tests/golden/raw_vitg_224_w1: 1.05e-3 with the WHOLE head in split precision), and half of that is injected by
 # the first quarter of the blocks (later blocks amplify it): their linear layers run in split precision (PackedWeights.enc_split_blocks).
 _RAW_VITG_ENC_SPLIT_BLOCKS = 8
+_SSI_DEEP_ENC_SPLIT_BLOCKS = 8
 
 
 def _encoder_split_policy(mode, encoder, final_act):
@@ -168,7 +169,14 @@ def _encoder_split_policy(mode, encoder, final_act):
     if mode == "auto" and _os.environ.get("ADA_ENC_SPLIT") is not None:
         mode = int(_os.environ["ADA_ENC_SPLIT"])
     if mode == "auto":
-        return _RAW_VITG_ENC_SPLIT_BLOCKS if (final_act == "relu" and encoder == "vitg") else 0
+        if final_act == "relu" and encoder == "vitg":
+            return _RAW_VITG_ENC_SPLIT_BLOCKS
+        # 'ssi' heads (no sigmoid to compress the logit noise) on the deep encoders: with the head already in split precision the encoder's operand
+        # rounding is what is left -- ViT-L at 518^2: 0.82e-3 / 0.84e-3 / 1.09e-3 on three weight draws with every block in single precision,
+        # 4.7e-4 ... 5.6e-4 with the first 8 in split precision (profiles/r04_q_ssi_heads_on_deep_encoders.txt).  ViT-B sits at 4.9e-4 without.
+        if final_act == "none" and encoder in ("vitl", "vitg"):
+            return _SSI_DEEP_ENC_SPLIT_BLOCKS
+        return 0
     return int(mode)
 
 

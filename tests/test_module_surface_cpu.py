@@ -28,7 +28,7 @@ def test_amodal_state_dict_matches_reference_schema(key):
     assert "pixel_mean" not in m.state_dict() and m.pixel_mean.shape == (3, 1, 1)
 
 
-@pytest.mark.parametrize("enc,feat,oc", [("vits", 64, [48, 96, 192, 384]), ("vitg", 384, [1536] * 4)])
+@pytest.mark.parametrize("enc,feat,oc", [("vits", 64, [48, 96, 192, 384]), ("vitb", 128, [96, 192, 384, 768]), ("vitl", 256, [256, 512, 1024, 1024]), ("vitg", 384, [1536] * 4)])
 def test_raw_state_dict_matches_reference_schema(enc, feat, oc):
     with torch.device("meta"):
         m = RawDepthAnythingV2(encoder=enc, features=feat, out_channels=oc)
@@ -113,3 +113,18 @@ def test_product_package_never_imports_the_oracle():
     for f in ("infer.py",):
         src = open(os.path.join(os.path.dirname(GOLDEN_DIR), "..", f)).read()
         assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_encoder_precision_policy_table(monkeypatch):
+    """Which models run the linear layers of their leading transformer blocks in split precision by default ("auto"): the unbounded heads on
+    the deep encoders -- raw ViT-G (ReLU head) and the 'ssi' (no activation) head on ViT-L -- because nothing compresses the encoder's operand noise
+    there (profiles/r04_e_raw_vitg_precision.txt, r04_q_ssi_heads_on_deep_encoders.txt); the benchmarked sigmoid models none."""
+    from src.models.amodalsynthdrive.depth_anything_v2.dpt import _encoder_split_policy
+    monkeypatch.delenv("ADA_ENC_SPLIT", raising=False)
+    for enc in ("vits", "vitb", "vitl"):
+        assert _encoder_split_policy("auto", enc, "sigmoid") == 0
+    assert _encoder_split_policy("auto", "vitl", "none") == 8 and _encoder_split_policy("auto", "vitb", "none") == 0
+    assert _encoder_split_policy("auto", "vitg", "relu") == 8 and _encoder_split_policy("auto", "vitl", "relu") == 0
+    assert _encoder_split_policy(5, "vitl", "sigmoid") == 5
+    monkeypatch.setenv("ADA_ENC_SPLIT", "3")
+    assert _encoder_split_policy("auto", "vitl", "sigmoid") == 3 and _encoder_split_policy(0, "vitl", "none") == 0

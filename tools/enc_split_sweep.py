@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""Raw ViT-G parity against the number of leading transformer blocks whose linear layers run in split precision (module.encoder_precision =
-K) and the head policy, on every raw ViT-G fixture; --time adds the 8 x 1022^2 step (BASELINE config 5) per setting.
-    python tools/enc_split_sweep.py [--time] [fixture ...]"""
+"""Parity against the number of leading transformer blocks whose linear layers run in split precision (module.encoder_precision = K) and the
+head policy, on every raw ViT-G fixture (default) or the named fixtures (raw or amodal); --time adds the 8 x 1022^2 step (BASELINE config 5)
+per setting.
+    python tools/enc_split_sweep.py [--time] [fixture ...]        (KS=0,4,8 HEADS=auto in the environment select the grid)"""
 import os
 import sys
 import time
@@ -27,19 +28,21 @@ def main():
         model = build_product_model(case)
         model.load_state_dict(synth_state_dict(model, meta), strict=True)
         model = model.cuda()
-        x = case_inputs(case)[0].cuda()
+        x, grgb, mask, obs = (t.cuda() for t in case_inputs(case))
+        eng_owner = model if case["kind"] == "raw" else model.encoder       # the module that carries the engine and its precision attributes
+        run = (lambda inp: model(inp)) if case["kind"] == "raw" else (lambda inp: model(inp, guide_rgb=grgb, guide_mask=mask, observation=obs))
         st = case["stride"]
         x8 = case_inputs(dict(case, B=8, seed=11))[0].cuda() if (do_time and name == "raw_vitg_1022") else None
         for head in HEADS:
             for K in KS:
-                model.head_precision = head
-                model.encoder_precision = K
-                object.__setattr__(model, "_engine_obj", None)
-                object.__setattr__(model, "_engine_stamp", None)
+                eng_owner.head_precision = head
+                eng_owner.encoder_precision = K
+                object.__setattr__(eng_owner, "_engine_obj", None)
+                object.__setattr__(eng_owner, "_engine_stamp", None)
                 torch.cuda.empty_cache()
                 torch.cuda.reset_peak_memory_stats()
                 with torch.no_grad():
-                    out = model(x)
+                    out = run(x)
                 line = f"{name:22s} head=[{head:40s}] first {K:2d} blocks split: rel-L1 {rel_l1(out[..., ::st, ::st].cpu(), gold):.3e}"
                 if x8 is not None:
                     with torch.no_grad():

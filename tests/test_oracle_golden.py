@@ -12,7 +12,7 @@ import torch
 
 from _cases import case_inputs, golden_names, load_golden, oracle_forward, schema_state_dict
 
-SLOW_ONLY = ("raw_vitg_1022", "vitl_714x1022", "vitl_1022", "vitl_ssi_1022", "vitb_1022")
+SLOW_ONLY = ("raw_vitg_1022", "vitl_714x1022", "vitl_1022", "vitl_ssi_1022", "vitb_1022", "vitl_714x1022_heavy", "vitb_714x1022_heavy")
 ORDER = sorted(golden_names(), key=lambda n: ("vitl" in n or "vitg" in n, n))
 
 

@@ -3,4 +3,4 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r4ad
 O=$PWD/gpurun_out/r4ad
-timeout 600 python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "raw_vits_518_heavy_w1 or vits_ssi_518_heavy_w1 or vitb_ssi_518_heavy_w1" 2>&1 | grep "rel-L1\|passed\|failed" | tee $O/new_fixtures.txt
+timeout 600 python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "714x1022_heavy" 2>&1 | grep "rel-L1\|passed\|failed" | tee $O/new_fixtures.txt

@@ -64,7 +64,9 @@ LN_EPS = 1e-6
 # "rs0" / "rs1" / "rs3" = resize_layers (ConvT 4x4, ConvT 2x2, conv3x3 stride 2), "ip<i>" = input_projection conv of level i,
 # "rn<i>" = layer<i+1>_rn, "rcu<i>" = the ResidualConvUnit convs of refinenet<i+1>, "out<i>" = its 1x1 out_conv, "oc1" / "oc2" = the tail
 # convs.  Level 0 is the finest grid (4x the patch grid), level 3 the coarsest.  HEAD_ALIASES name whole families.
-HEAD_GROUPS = ("proj", "rs0", "rs1", "rs3") + tuple(f"{f}{i}" for f in ("ip", "rn", "rcu", "out") for i in range(4)) + ("oc1", "oc2")
+# "projw" = the four 1x1 projects with WEIGHT-ONLY split precision ([w_hi | w_lo] against the plain LayerNorm output walked twice, ada_igemm a_wrap:
+# the weight's rounding error goes, the activation's stays; 2x the MACs instead of 3x and no [hi | lo] copy of the tap).  Ignored when "proj" is set.
+HEAD_GROUPS = ("proj", "projw", "rs0", "rs1", "rs3") + tuple(f"{f}{i}" for f in ("ip", "rn", "rcu", "out") for i in range(4)) + ("oc1", "oc2")
 HEAD_ALIASES = {"tok": ("proj", "rs0", "rs1", "rs3"), "ip": tuple(f"ip{i}" for i in range(4)), "rn": tuple(f"rn{i}" for i in range(4)),
                 "rcu": tuple(f"rcu{i}" for i in range(4)), "out": tuple(f"out{i}" for i in range(4))}
 # ada_dpt_tail_fwd (resize + output_conv2 fused; the up-sampled map "fin" -- 2.2 GB at ViT-L bs=32 -- is neither allocated nor written) is the
@@ -298,7 +300,13 @@ class PackedWeights:
                 self.ro_b.append(f32(f"{h}readout_projects.{i}.0.bias"))
         self.oc = [sd[f"{h}projects.{i}.weight"].shape[0] for i in range(4)]
         self.features = sd[h + "scratch.layer1_rn.weight"].shape[0]
-        self.proj_w = [lin(f32(f"{h}projects.{i}.weight"), "proj") for i in range(4)]
+        def proj_lin(w):   # "projw": [w_hi | w_lo] against the plain tap (HEAD_GROUPS comment); "proj" (full split) takes precedence
+            w2 = w.reshape(w.shape[0], -1)
+            if "projw" in self.split and "proj" not in self.split and w2.shape[1] % 64 == 0:
+                hi = w2.to(op)
+                return torch.cat([hi, (w2 - hi.float()).to(op)], dim=1).contiguous()
+            return lin(w, "proj")
+        self.proj_w = [proj_lin(f32(f"{h}projects.{i}.weight")) for i in range(4)]
         self.proj_b = [f32(f"{h}projects.{i}.bias") for i in range(4)]
         self.rs0_w, self.rs0_b = convT(f32(h + "resize_layers.0.weight"), f32(h + "resize_layers.0.bias"), 4, "rs0")
         self.rs1_w, self.rs1_b = convT(f32(h + "resize_layers.1.weight"), f32(h + "resize_layers.1.bias"), 2, "rs1")
@@ -578,6 +586,8 @@ class DepthEngine:
             return dict(K=K, lda=a_width, a_dup_seg=0)
         if 2 * K == 3 * taps * a_width:
             return dict(K=K, lda=a_width, a_dup_seg=a_width // 2)
+        if taps == 1 and K == 2 * a_width:     # [w_hi | w_lo] against a plain operand walked twice (weight-only split)
+            return dict(K=K, lda=a_width, a_dup_seg=0, a_wrap=a_width)
         raise HipExtError(f"packed weights with K={K} do not fit an operand of width {a_width} ({taps} tap(s))")
 
     @classmethod

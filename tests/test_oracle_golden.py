@@ -3,7 +3,7 @@ by oracle/make_golden.py from /root/reference).  This is what pins the oracle; i
 
 Cost control (the whole CPU suite has to stay within a few minutes): the batch-8 / batch-32 fixtures replay ONE image
 of the batch (the model is batch-invariant; reference measured 1.2e-7), and the ViT-G 1022x1022 fixture (two minutes
-of CPU per forward) and the ViT-L 714x1022 one are replayed only when ADA_SLOW_TESTS=1 -- its oracle-vs-reference agreement (max abs 0.0) was
+of CPU per forward), the other 1022-pixel ones and the extra draws of the ViT-L families are replayed only when ADA_SLOW_TESTS=1 -- its oracle-vs-reference agreement (max abs 0.0) was
 asserted by oracle/make_golden.py when the fixture was generated and is recorded in the fixture's metadata."""
 import os
 
@@ -12,7 +12,9 @@ import torch
 
 from _cases import case_inputs, golden_names, load_golden, oracle_forward, schema_state_dict
 
-SLOW_ONLY = ("raw_vitg_1022", "vitl_714x1022", "vitl_1022", "vitl_ssi_1022", "vitb_1022", "vitl_714x1022_heavy", "vitb_714x1022_heavy")
+SLOW_ONLY = ("raw_vitg_1022", "vitl_714x1022", "vitl_1022", "vitl_ssi_1022", "vitb_1022", "vitl_714x1022_heavy", "vitb_714x1022_heavy",
+             # further draws of ViT-L families that have a replayed fixture already (vitl_ssi_518, raw_vitl_518, vitl_518): 15-20 s of CPU each
+             "vitl_ssi_518_w1", "vitl_ssi_518_w2", "vitl_ssi_518_heavy", "vitl_518_heavy", "raw_vitl_518_heavy", "raw_vitl_518_heavy_w1")
 ORDER = sorted(golden_names(), key=lambda n: ("vitl" in n or "vitg" in n, n))
 
 

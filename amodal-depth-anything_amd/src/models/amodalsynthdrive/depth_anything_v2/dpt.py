@@ -120,7 +120,8 @@ _FOLD_LN_DEFAULT = _os.environ.get("ADA_FOLD_LN", "0") == "1"
 
 
 # Head precision policy for "auto" (measured on MI355X against the reference goldens, profiles/r03_e_head_split_sweep.txt):
-#   sigmoid heads of ViT-B / ViT-L (the benchmarked models)  -> single precision everywhere (6.6e-4 .. 8.2e-4)
+#   sigmoid heads of ViT-B / ViT-L (the benchmarked models)  -> single precision but the 1x1 out_convs of refinenet2-4 (round 4) and, on ViT-L, the
+#                                                               projects' weights ("projw", round 4)
 #   ViT-S (64-feature head) and every 'ssi' head             -> every head contraction in split precision (1.8e-3 -> 6.9e-4; cheap models)
 #   raw (ReLU) ViT-G, features 384                           -> only the contractions whose operand rounding shows in the output and that are
 #                                                               cheap: the tail conv, the 1x1 out_convs and projects, the three coarse
@@ -148,7 +149,10 @@ def _head_split_policy(mode, encoder, final_act):
             # round 4: the 1x1 out_convs of refinenet2-4 in split precision -- the largest single group of the head's operand noise in the
             # ViT-B / ViT-L oracle studies and all but free (K = features): worst fixture 9.25e-4 -> 6.9e-4, throughput unchanged
             # (profiles/r04_h_sigmoid_head_out_conv_split.txt).  refinenet1's out_conv is part of output_conv1's tap maps (engine OC1_COMMUTE)
-            return frozenset(_SIGMOID_SPLIT)
+            # ViT-L also runs its four 1x1 projects against [w_hi | w_lo] weights ("projw", weight-only split: 2x their 0.25 TFLOP per bs=32 step,
+            # 0.4 % of it): the heavy-tailed 714 x 1022 stress fixture 8.9e-4 -> 6.9e-4, the benchmarked batch 6.17e-4 -> 5.94e-4; on ViT-B the
+            # projects are not where the noise sits (9.0e-4 -> 8.8e-4 on its stress fixture, profiles/r04_r_*), so it keeps the three out_convs only
+            return frozenset(_SIGMOID_SPLIT + (("projw",) if encoder == "vitl" else ()))
         if final_act == "relu" and encoder == "vitg":
             return frozenset(_RAW_VITG_SPLIT)
         return frozenset(HEAD_GROUPS)

@@ -448,14 +448,17 @@ __global__ __launch_bounds__(256) void tapsum_resize_kernel(TapSumArgs p) {
     if (tid < TS_TH + 2) {
         const int Y = ty0 - 1 + tid;
         const bool ok = Y >= 0 && Y < p.ho;
-        const float f = p.sy * (float)(ok ? Y : 0);
-        const int y0 = (int)f, y1 = y0 + (y0 < p.hi - 1 ? 1 : 0);
+        // a fine row / column outside the image (the convolution's zero padding) carries weight 0, but the compute loop still issues the LDS
+        // reads of a masked COLUMN: its offsets must point at staged data (the patch origin), never below it -- a source index of 0 would give
+        // (0 - px0) * PIXB < 0, i.e. bytes of another tap's slab or of the tables below, and 0 * Inf / NaN bit patterns poison the edge pixel
+        const float f = ok ? p.sy * (float)Y : (float)py0;
+        const int y0 = (int)f, y1 = y0 + (ok && y0 < p.hi - 1 ? 1 : 0);
         rowinfo[tid] = make_float4(__builtin_bit_cast(float, (y0 - py0) * p.pw * PIXB), __builtin_bit_cast(float, (y1 - py0) * p.pw * PIXB), f - (float)y0, ok ? 1.0f : 0.0f);
     } else if (tid >= 64 && tid < 64 + TS_TW + 2) {
         const int i = tid - 64, X = tx0 - 1 + i;
         const bool ok = X >= 0 && X < p.wo;
-        const float f = p.sx * (float)(ok ? X : 0);
-        const int x0 = (int)f, x1 = x0 + (x0 < p.wi - 1 ? 1 : 0);
+        const float f = ok ? p.sx * (float)X : (float)px0;
+        const int x0 = (int)f, x1 = x0 + (ok && x0 < p.wi - 1 ? 1 : 0);
         colinfo[i] = make_float4(__builtin_bit_cast(float, (x0 - px0) * PIXB), __builtin_bit_cast(float, (x1 - px0) * PIXB), f - (float)x0, ok ? 1.0f : 0.0f);
     }
     float4 acc[TS_TH * TS_TW / 8];

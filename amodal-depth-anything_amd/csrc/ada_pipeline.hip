@@ -33,6 +33,38 @@ __global__ __launch_bounds__(1024) void minmax_kernel(const float* __restrict__ 
     }
 }
 
+// Per-image sums of a sigmoid-head depth map s in (0, 1): (sum s, sum s (1 - s)) -- the two moments the engine's precision ladder needs.  The relative
+// L1 of a sigmoid output against its fp32 reference is  mean|sigma'(z) dz| / mean s = mean(s (1 - s) |dz|) / mean(s): the ratio of the two sums is the
+// factor by which the sigmoid compresses the head's logit error for THIS image (0.3-0.5 for maps centred in (0, 1), -> 1 as the map approaches 0).
+// grid (chunks, batch): every workgroup sums a contiguous chunk in a fixed order (no atomics: bit-reproducible); the host adds the chunk sums.
+__global__ __launch_bounds__(1024) void depth_stats_kernel(const float* __restrict__ in, long n_per_image, float* __restrict__ out) {
+    __shared__ float s1[16], s2[16];
+    const int chunks = gridDim.x, c = blockIdx.x, b = blockIdx.y;
+    const long per = (n_per_image + chunks - 1) / chunks;
+    const long lo = (long)c * per, hi = lo + per < n_per_image ? lo + per : n_per_image;
+    const float* src = in + (long)b * n_per_image;
+    float a = 0.0f, q = 0.0f;
+    for (long i = lo + threadIdx.x; i < hi; i += 1024) {
+        const float v = src[i];
+        a += v;
+        q += v * (1.0f - v);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a += __shfl_xor(a, o);
+        q += __shfl_xor(q, o);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s1[w] = a; s2[w] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i) { a += s1[i]; q += s2[i]; }
+        out[((long)b * chunks + c) * 2] = a;
+        out[((long)b * chunks + c) * 2 + 1] = q;
+    }
+}
+
 // norm = (d - min) / (max - min)   (reference infer.py:22);  obs = norm * 2 - 1   (infer.py:92)
 __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ in, const float* __restrict__ minmax, long n_per_image,
                                                         float* __restrict__ norm, float* __restrict__ obs) {
@@ -126,6 +158,13 @@ extern "C" int ada_minmax_fwd(const float* in, int32_t batch, int64_t n_per_imag
     ADA_REQUIRE(batch > 0 && n_per_image > 0, ADA_EINVAL, "ada_minmax_fwd: bad shape");
     hipLaunchKernelGGL(minmax_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, in, (long)n_per_image, minmax);
     return ada_check_launch("ada_minmax_fwd");
+}
+
+extern "C" int ada_depth_stats_fwd(const float* in, int32_t batch, int64_t n_per_image, int32_t chunks, float* sums, void* stream) {
+    ADA_REQUIRE(in && sums, ADA_EINVAL, "ada_depth_stats_fwd: null pointer");
+    ADA_REQUIRE(batch > 0 && batch <= 65535 && n_per_image > 0 && chunks > 0 && chunks <= 1024, ADA_EINVAL, "ada_depth_stats_fwd: bad shape (batch=%d chunks=%d)", batch, chunks);
+    hipLaunchKernelGGL(depth_stats_kernel, dim3(chunks, batch), dim3(1024), 0, (hipStream_t)stream, in, (long)n_per_image, sums);
+    return ada_check_launch("ada_depth_stats_fwd");
 }
 
 extern "C" int ada_normalize_fwd(const float* in, const float* minmax, int32_t batch, int64_t n_per_image, float* norm, float* obs,

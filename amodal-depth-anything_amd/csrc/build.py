@@ -14,7 +14,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(HERE, "..", "..", "tools"))
+sys.path.insert(0, HERE)     # isa_guard.py lives next to this file: the package builds without the repository's tools/
 SOURCES = ["ada_api.hip", "ada_igemm.hip", "ada_attention.hip", "ada_elementwise.hip", "ada_pipeline.hip", "ada_eval.hip", "ada_tail.hip"]
 HEADERS = ["ada_common.h", "ada_igemm_pipe4.inc", os.path.join("..", "..", "include", "ada_hip.h")]
 ARCH = "gfx950"
@@ -34,7 +34,7 @@ NO_SCRATCH = {"ada_tail.hip", "ada_igemm.hip"}
 # Round 4: the wrong results above were root-caused (profiles/r04_a_tail_inflight_register_root_cause.txt) -- NOT a hardware hazard of packed
 # fp32 beside MFMAs (tools/ubench/pk_f32_beside_mfma.hip: 0 mismatches) but the compiler copying registers that the kernel's inline-asm
 # fetches were still writing: with SLP on, the allocator parks a source row in other registers with v_mov_b64 placed ABOVE the hand-counted
-# s_waitcnt.  The flag only happens to avoid that allocation, so the build now CHECKS the generated ISA (tools/isa_guard.py) and fails if
+# s_waitcnt.  The flag only happens to avoid that allocation, so the build now CHECKS the generated ISA (isa_guard.py, next to this file) and fails if
 #   * any instruction of an ISA_GUARD["inflight"] file touches a VGPR while a load into it may still be outstanding,
 #   * an ISA_GUARD["no_packed_f32"] file contains v_pk_*_f32 (the configuration the kernel was validated in),
 #   * in an ISA_GUARD["agpr_after_pipe4"] file anything but v_accvgpr_read touches an AGPR between the end of the generated 4-wave GEMM
@@ -52,7 +52,7 @@ def _hipcc():
 
 def _digest(defines):
     h = hashlib.sha256()
-    for name in SOURCES + HEADERS + ["build.py", os.path.join("..", "..", "tools", "isa_guard.py")]:   # build.py itself: flags are part of the digest
+    for name in SOURCES + HEADERS + ["build.py", "isa_guard.py"]:   # build.py itself: flags are part of the digest
         with open(os.path.join(HERE, name), "rb") as f:
             h.update(f.read())
     h.update((" ".join(defines) + os.environ.get("ADA_EXTRA_FLAGS", "")).encode())

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Build-time ISA guards for kernels whose correctness depends on things the compiler is never told (csrc/build.py runs them; they
-can be run by hand on any gfx9 assembly listing:  python tools/isa_guard.py file.s [--kernel substr] [--no-packed-f32]).
+can be run by hand on any gfx9 assembly listing:  python amodal-depth-anything_amd/csrc/isa_guard.py file.s [--kernel substr] [--no-packed-f32]).
 
 1. **In-flight registers.**  ada_tail.hip fetches with inline-asm ``global_load_dwordx4`` into C++ variables and waits with a hand-counted
    ``s_waitcnt vmcnt(N)``.  The compiler does not know that those registers are still being written: to it the value exists as soon as the
@@ -71,6 +71,13 @@ class Counters:
         self.lgkm = [(set(r), ln, k) for r, ln, k in other.lgkm] if other else []
 
 
+def _returns(ins):
+    """A global / buffer / flat atomic returns its pre-operation value (and therefore writes its destination VGPRs) when the return bit is set:
+    spelled ``sc0`` on gfx940 / gfx950, ``glc`` on older gfx9 listings."""
+    toks = ins.replace(",", " ").split()
+    return "sc0" in toks or "glc" in toks
+
+
 def _step(c, no, ins, report):
     """Advances the counters over one instruction; appends (line, instruction, registers, lines of the pending loads) to report."""
     op = ins.split()[0]
@@ -93,7 +100,7 @@ def _step(c, no, ins, report):
     dst = set()
     touched = _regs(ins)
     to_lds = "_lds_" in op or " lds" in ins   # LDS-DMA (global_load_lds_*, buffer_load ... lds): counted by vmcnt, no VGPR destination
-    if is_vmem and ("load" in op or ("atomic" in op and "glc" in ins.split())) and not to_lds:
+    if is_vmem and ("load" in op or ("atomic" in op and _returns(ins))) and not to_lds:
         dst = _regs(ins[len(op):].split(",")[0])
     if is_lds and (op.startswith("ds_read") or "_rtn" in op or op.startswith("ds_bpermute") or op.startswith("ds_permute") or op.startswith("ds_swizzle")):
         dst = _regs(ins[len(op):].split(",")[0])
@@ -113,7 +120,11 @@ def _step(c, no, ins, report):
 
 
 def check_inflight(body):
-    """Linear pass + one extra trip around every backward branch with the counter state found at the branch."""
+    """Linear pass + one extra trip around every backward branch with the counter state found at the branch.
+    Control-flow limits (known false negatives, by construction): a FORWARD branch is treated as fall-through -- the state that reaches its target
+    over the taken edge is not simulated -- and a loop is walked once more with the state at its back edge, not to a fixed point.  The guarded
+    kernels (fused tail, attention) keep their hand-counted fetches inside straight-line loop bodies, which is the shape this covers; the
+    -fno-slp-vectorize flag on ada_tail.hip stays as the second line of defence."""
     report, c = [], Counters()
     labels = {}
     state_at = {}

@@ -35,6 +35,7 @@ from . import dpt_tail as k_dpt_tail
 from . import igemm as _igemm
 from . import layernorm as _layernorm
 from . import debug_epoch, instrumented, operand_dtype
+from . import depth_stats as k_depth_stats
 from . import patchify as k_patchify
 from . import pos_embed_resize as k_pos_embed_resize
 from . import rowstats_finalize as k_rowstats_finalize
@@ -90,6 +91,7 @@ SUBPIXEL = os.environ.get("ADA_SUBPIXEL", "1") == "1"
 # the proj / fc2 launch itself -- the last-arriving tile of every 256-row panel normalises the panel it has just completed -- instead of by a
 # separate pass of all CUs over the fp32 residual stream.  ADA_LN_TAIL=0: separate ada_layernorm launches.
 LN_TAIL = os.environ.get("ADA_LN_TAIL", "0") == "1"
+STAT_CHUNKS = 8
 OC1_COMMUTE = int(os.environ.get("ADA_OC1_COMMUTE", "16"))     # 0: off; 16: operand-typed tap maps (default); 32: fp32 tap maps (no parity gain, slower)
 
 
@@ -124,8 +126,11 @@ class PackedWeights:
     with the *raw* model's key names (``pretrained.*``, ``depth_head.*``)."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], encoder: str, guided: bool, amodal_head: bool, split_head=False,
-                 fold_ln: bool = False, enc_split_blocks: int = 0):
+                 fold_ln: bool = False, enc_split_blocks: int = 0, head_only: bool = False, tap_split: bool = False):
         op = operand_dtype()
+        # head_only: the DPT head's weights only (the second rung of the precision ladder, DepthEngine._escalate, re-runs the head from the taps)
+        # tap_split: the four taps are stored [hi | lo] whatever the head's own policy -- so that a split-precision head can be re-run from them
+        self.head_only, self.tap_split = bool(head_only), bool(tap_split)
         cfg = VIT[encoder]
         D = cfg["dim"]
         self.encoder, self.guided, self.amodal_head = encoder, guided, amodal_head
@@ -179,9 +184,16 @@ class PackedWeights:
             return lin(wt), b.repeat(s * s).contiguous()
 
         p = "pretrained."
+        self.blocks = []
+        self.guide_channels = 0
+        if not head_only:
+            self._pack_encoder(sd, f32, lin, op, D, guided)
+        self._pack_head(sd, f32, lin, conv3, op, D, amodal_head)
+
+    def _pack_encoder(self, sd, f32, lin, op, D, guided):
+        p = "pretrained."
         w_rgb = f32(p + "patch_embed.proj.weight").reshape(D, -1)
         b_pe = f32(p + "patch_embed.proj.bias")
-        self.guide_channels = 0
         if guided:
             w_g = f32(p + "patch_embed_guidance.proj.weight")
             self.guide_channels = w_g.shape[1]
@@ -256,6 +268,7 @@ class PackedWeights:
             self.blocks.append(blk)
         self.norm_w, self.norm_b = f32(p + "norm.weight"), f32(p + "norm.bias")
 
+    def _pack_head(self, sd, f32, lin, conv3, op, D, amodal_head):
         lin1, conv3_1 = lin, conv3
 
         def triple(w2d):   # [..., K] fp32, K already padded to a multiple of 64
@@ -393,7 +406,8 @@ class PackedWeights:
 
 
 class Workspace:
-    def __init__(self, pw_: PackedWeights, B: int, H: int, W: int, device):
+    def __init__(self, pw_: PackedWeights, B: int, H: int, W: int, device, head_only: bool = False):
+        """head_only: the buffers of the DPT head and the four taps only (the precision ladder's second rung re-runs the head from the taps)."""
         op = operand_dtype()
         self.B, self.H, self.W = B, H, W
         ph, pw = H // PATCH, W // PATCH
@@ -406,26 +420,30 @@ class Workspace:
         Fp = _r64(Fch)
         def mm(group):     # an op-typed head tensor holds [hi | lo] segments iff the contraction that READS it is in a split group
             return 2 if group in pw_.split else 1
-        m = mm("proj")
+        # the taps are [hi | lo] when the projects read them in split precision -- or when the engine keeps them so for the ladder's second rung
+        m = 2 if (pw_.tap_split or "proj" in pw_.split) else 1
+        self.tap_seg = D if m == 2 else 0
         first = "ip" if pw_.amodal_head else "rn"     # the contraction family that reads the reassembled maps L[i]
 
         def z(*shape, dtype=op):
             return torch.zeros(*shape, dtype=dtype, device=device)
 
-        self.a_pe = z(P, 2 * pw_.pe_seg)     # split-precision patches: [hi | lo]
-        self.x = z(T, D, dtype=torch.float32)
-        # LayerNorm output ([hi | lo] column segments for the split-precision blocks: PackedWeights.enc_split_blocks); with folded LayerNorms: the
-        # operand-typed copy of the residual stream itself
-        self.y = z(T, 2 * D if pw_.enc_split_blocks > 0 else D)
-        if pw_.fold_ln:
-            self.part = z(T, D // 64, 2, dtype=torch.float32)    # per-row partial (sum, sum of squares), one slot per 64 columns
-            self.stats = z(T, 2, dtype=torch.float32)            # (mean, rstd) per row
-        self.ln_cnt = torch.zeros(T // 128 + 2, dtype=torch.int32, device=device)     # per-row-panel tickets of the LayerNorm tail (kernel-reset)
-        self.qkv = z(T, 3 * D)
-        self.o = z(T, D)
-        hidden = pw_.blocks[0]["hidden"]
-        self.hd = z(T, hidden)
+        if not head_only:
+            self.a_pe = z(P, 2 * pw_.pe_seg)     # split-precision patches: [hi | lo]
+            self.x = z(T, D, dtype=torch.float32)
+            # LayerNorm output ([hi | lo] column segments for the split-precision blocks: PackedWeights.enc_split_blocks); with folded LayerNorms: the
+            # operand-typed copy of the residual stream itself
+            self.y = z(T, 2 * D if pw_.enc_split_blocks > 0 else D)
+            if pw_.fold_ln:
+                self.part = z(T, D // 64, 2, dtype=torch.float32)    # per-row partial (sum, sum of squares), one slot per 64 columns
+                self.stats = z(T, 2, dtype=torch.float32)            # (mean, rstd) per row
+            self.ln_cnt = torch.zeros(T // 128 + 2, dtype=torch.int32, device=device)     # per-row-panel tickets of the LayerNorm tail (kernel-reset)
+            self.qkv = z(T, 3 * D)
+            self.o = z(T, D)
+            hidden = pw_.blocks[0]["hidden"]
+            self.hd = z(T, hidden)
         self.taps = [z(P, m * D) for _ in range(4)]
+        self.stat_sums = z(B, STAT_CHUNKS, 2, dtype=torch.float32)     # per-image (sum s, sum s (1 - s)) of the depth map, in chunks (ada_depth_stats_fwd)
         if pw_.readout:
             self.cls_op = [z(B, m * D) for _ in range(4)]                          # final-LayerNorm'd class tokens, operand-typed
             self.cls_bias = [z(B, D, dtype=torch.float32) for _ in range(4)]       # W_cls cls + b per image
@@ -519,8 +537,9 @@ class _GraphedForward:
             raise RuntimeError("workspace changed during graph capture")
         self.lock = threading.Lock()
 
-    def __call__(self, x: torch.Tensor, guide: Optional[torch.Tensor]) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, guide: Optional[torch.Tensor], post=None) -> torch.Tensor:
         # the static input / output buffers are shared by every caller of this shape: copy-in, replay and copy-out are one critical section
+        # (`post(ws, out)`: the engine's precision ladder, which reads the taps this replay left in the graph's workspace)
         with self.lock:
             self.x.copy_(x)
             if self.guide is not None:
@@ -528,16 +547,26 @@ class _GraphedForward:
                     raise HipExtError(f"guide tensor of shape {tuple(self.guide.shape)} required")
                 self.guide.copy_(guide)
             self.graph.replay()
-            return self.out.clone()
+            out = self.out.clone()
+            return out if post is None else post(self.ws, out)
 
 
 class DepthEngine:
     """Runs one forward.  ``final_act``: 'sigmoid' | 'relu' | 'none'."""
 
-    def __init__(self, weights: PackedWeights, final_act: str, normalise_input: bool):
+    def __init__(self, weights: PackedWeights, final_act: str, normalise_input: bool, ladder: Optional[dict] = None):
         self.w = weights
         self.final_act = {"sigmoid": ACT_SIGMOID, "relu": ACT_RELU, "none": ACT_NONE}[final_act]
         self.normalise_input = normalise_input
+        # Precision ladder of the sigmoid heads (see _escalate): dict(r=<threshold on sum s(1-s) / sum s>, make=<callable -> head-only PackedWeights
+        # in split precision>) or None.  The first rung -- this engine's own weights -- must keep its taps [hi | lo] (PackedWeights.tap_split).
+        self.ladder = ladder if (ladder is not None and final_act == "sigmoid") else None
+        if self.ladder is not None and not weights.tap_split and "proj" not in weights.split:
+            raise HipExtError("precision ladder: the engine's weights must be packed with tap_split=True")
+        self._w_hi: Optional[PackedWeights] = None
+        self._ws_hi: "OrderedDict[tuple, Workspace]" = OrderedDict()
+        self.escalated = 0            # images the ladder has re-run so far
+        self.last_ratio = None        # per-image sum s(1-s) / sum s of the most recent call (CPU tensor), None when the ladder is off
         self._ws: "OrderedDict[tuple, Workspace]" = OrderedDict()
         self._graphs: "OrderedDict[tuple, object]" = OrderedDict()   # key -> _GraphedForward | False (capture refused) | int (sightings)
         self._lock = threading.Lock()
@@ -577,11 +606,19 @@ class DepthEngine:
 
     # ---- small helpers over igemm ---------------------------------------------------------
     @staticmethod
-    def _kdup(a_width: int, w: torch.Tensor, taps: int = 1) -> dict:
+    def _kdup(a_width: int, w: torch.Tensor, taps: int = 1, a_seg: int = 0) -> dict:
         """K / lda / a_dup_seg of a contraction whose A rows are ``a_width`` wide and whose packed weights are ``w`` [N, K]: either a plain
         operand (K == taps * a_width) or a split one -- [hi | lo] activations against [w_hi | w_hi | w_lo] weights, 2 K == 3 taps a_width,
         the third k segment re-reading the first (ada_igemm a_dup_seg)."""
         K = int(w.shape[1])
+        if a_seg:     # the A rows ARE [hi | lo] segments of width a_seg (a tap of an engine that keeps them so): the weights decide what is walked
+            if K == 3 * a_seg:
+                return dict(K=K, lda=a_width, a_dup_seg=a_seg)
+            if K == a_seg:                       # single-precision contraction: the hi half only
+                return dict(K=K, lda=a_width, a_dup_seg=0)
+            if K == 2 * a_seg:                   # [w_hi | w_lo] against the hi half walked twice
+                return dict(K=K, lda=a_width, a_dup_seg=0, a_wrap=a_seg)
+            raise HipExtError(f"packed weights with K={K} do not fit a [hi | lo] operand with segments of {a_seg}")
         if K == taps * a_width:
             return dict(K=K, lda=a_width, a_dup_seg=0)
         if 2 * K == 3 * taps * a_width:
@@ -609,7 +646,7 @@ class DepthEngine:
         use = mode == "1" or (mode == "auto" and x.shape[0] * x.shape[-2] * x.shape[-1] <= GRAPH_AUTO_PIXELS)
         # replay bypasses the Python wrappers: with a KernelTimer or a tile log attached the launches must be issued one by one
         if not use or instrumented() or torch.cuda.is_current_stream_capturing():
-            return self._forward(x, guide, norm)
+            return self._escalate(None, self._forward(x, guide, norm))
         # the kernel variant / tile override / fused-tail switch in force at capture time are baked into the graph
         key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device), debug_epoch(), FUSED_TAIL, SUBPIXEL, OC1_COMMUTE, LN_TAIL, norm)
         with self._lock:
@@ -632,8 +669,62 @@ class DepthEngine:
                 while len(self._graphs) > max(1, MAX_GRAPHS):
                     self._graphs.popitem(last=False)
         if g is False:
-            return self._forward(x, guide, norm)
-        return g(x, guide)
+            return self._escalate(None, self._forward(x, guide, norm))
+        return g(x, guide, self._escalate if self.ladder is not None else None)
+
+    def _escalate(self, ws: Optional[Workspace], out: torch.Tensor) -> torch.Tensor:
+        """Second rung of the precision ladder (sigmoid heads).  The default policy runs the DPT head on single fp16 operands and
+        counts on the sigmoid to compress the logit error it leaves (~1.2e-3 mean absolute): in the north-star metric mean|a - b| / mean|b| that error
+        arrives multiplied by  r = sum s (1 - s) / sum s  of the image -- 0.3-0.5 for maps that span (0, 1), -> 1 for maps concentrated near 0, where the
+        single-precision head exceeds the 1e-3 bar (reference fixtures vitl_518_m10, vitb_518_zeros, ...).  r is computed from the output itself
+        (ada_depth_stats_fwd, one deterministic reduction); for the images whose r exceeds the threshold the HEAD ONLY (27 % of the FLOPs) is re-run
+        in split precision from the four taps, which this engine keeps [hi | lo] for the purpose, and its result replaces theirs.  The decision is a
+        pure function of the image's own first-rung output: deterministic, independent of the rest of the batch.  Costs one host read of 16 floats
+        per image (the forward's only synchronisation); off under stream capture (a caller's own HIP graph cannot hold a data-dependent branch)."""
+        lad = self.ladder
+        if lad is None:
+            return out
+        if torch.cuda.is_current_stream_capturing():
+            return out
+        B, H, W = out.shape[0], out.shape[-2], out.shape[-1]
+        if ws is None:
+            ws = self.workspace(B, H, W, out.device)
+        k_depth_stats(out, ws.stat_sums)
+        st = ws.stat_sums.cpu().double().sum(1)
+        ratio = st[:, 1] / st[:, 0].clamp_min(1e-300)
+        self.last_ratio = ratio
+        idx = torch.nonzero(ratio > lad["r"]).flatten()
+        if idx.numel() == 0:
+            return out
+        if self._w_hi is None:
+            self._w_hi = lad["make"]()
+        Be = int(idx.numel())
+        key = (Be, H, W, str(out.device))
+        ws2 = self._ws_hi.get(key)
+        if ws2 is None:
+            while len(self._ws_hi) >= max(1, MAX_WORKSPACES):
+                self._ws_hi.popitem(last=False)
+            ws2 = Workspace(self._w_hi, Be, H, W, out.device, head_only=True)
+            self._ws_hi[key] = ws2
+        else:
+            self._ws_hi.move_to_end(key)
+        own = ws2.taps
+        try:
+            if Be == B:
+                ws2.taps = ws.taps        # every image of the batch: the head reads the first rung's taps in place
+            else:
+                sel = idx.to(out.device)
+                for t in range(4):
+                    torch.index_select(ws.taps[t].view(B, -1), 0, sel, out=own[t].view(Be, -1))
+            hi = self._head(ws2, Be, self._w_hi)
+        finally:
+            ws2.taps = own
+        if Be == B:
+            out = hi
+        else:
+            out.index_copy_(0, idx.to(out.device), hi)
+        self.escalated += Be
+        return out
 
     def _forward(self, x: torch.Tensor, guide: Optional[torch.Tensor], norm: Optional[bool] = None) -> torch.Tensor:
         w = self.w
@@ -738,20 +829,20 @@ class DepthEngine:
                     # same statistics -- norm1(x) for all T rows into ws.y, norm(x) without the cls rows into the tap
                     nb = w.blocks[i + 1]
                     k_layernorm(ws.x, D, T, D, nb["ln1_w"], nb["ln1_b"], LN_EPS, out_op=ws.y, ld_op=ldy, split_seg=seg(nb), weight2=w.norm_w, bias2=w.norm_b,
-                                out2_op=tap, ld2_op=tap.shape[1], out2_group=N, out2_skip=1, split_seg2=D if "proj" in w.split else 0)
+                                out2_op=tap, ld2_op=tap.shape[1], out2_group=N, out2_skip=1, split_seg2=ws.tap_seg)
                     ln1_done = True
                 else:
                     k_layernorm(ws.x, D, P, D, w.norm_w, w.norm_b, LN_EPS, group_in=N, skip=1, out_op=tap, ld_op=tap.shape[1],
-                                split_seg=D if "proj" in w.split else 0)
+                                split_seg=ws.tap_seg)
                 if w.readout:   # the class token of every image (row b * N of the token matrix): input row stride N * D
                     j = taps.index(i)
                     k_layernorm(ws.x, N * D, B, D, w.norm_w, w.norm_b, LN_EPS, out_op=ws.cls_op[j], ld_op=ws.cls_op[j].shape[1],
-                                split_seg=D if "proj" in w.split else 0)
+                                split_seg=ws.tap_seg)
 
         return self._head(ws, B)
 
-    def _head(self, ws: Workspace, B: int) -> torch.Tensor:
-        w = self.w
+    def _head(self, ws: Workspace, B: int, w: Optional[PackedWeights] = None) -> torch.Tensor:
+        w = self.w if w is None else w
         D = w.dim
         ph, pw = ws.ph, ws.pw
         P = B * ph * pw
@@ -771,26 +862,26 @@ class DepthEngine:
             KDr = ws.taps[0].shape[1]
             Np = ph * pw
             for i in range(4):
-                k_igemm(M=B, N=D, k_alg=D, A=ws.cls_op[i], W=w.ro_wc[i], bias=w.ro_b[i], flags=EP_BIAS, out_f32=ws.cls_bias[i], ldo_f32=D, **self._kdup(KDr, w.ro_wc[i]))
+                k_igemm(M=B, N=D, k_alg=D, A=ws.cls_op[i], W=w.ro_wc[i], bias=w.ro_b[i], flags=EP_BIAS, out_f32=ws.cls_bias[i], ldo_f32=D, **self._kdup(KDr, w.ro_wc[i], a_seg=ws.tap_seg))
                 # one launch for the whole batch: the bias vector of row m is cls_bias[m // Np] (ada_igemm_args.bias_row_mod)
-                k_igemm(M=B * Np, N=D, k_alg=D, A=ws.taps[i], W=w.ro_wx[i], bias=ws.cls_bias[i], bias_row_mod=Np, **self._kdup(KDr, w.ro_wx[i]),
+                k_igemm(M=B * Np, N=D, k_alg=D, A=ws.taps[i], W=w.ro_wx[i], bias=ws.cls_bias[i], bias_row_mod=Np, **self._kdup(KDr, w.ro_wx[i], a_seg=ws.tap_seg),
                         flags=EP_BIAS | EP_GELU, out_op=ws.taps_ro[i], ldo_op=ws.taps_ro[i].shape[1], split_seg=S("proj", D))
             taps_in = ws.taps_ro
         # ---- reassemble: 1x1 project + resize (dpt.py:171-173) -> zero-bordered NHWC operand tensors -----
         KD = ws.taps[0].shape[1]
         for i, s_ in ((0, 4), (1, 2)):
             if i in w.sp:     # 1x1 project -> zero-bordered patch-grid tensor; the transposed conv runs inside the sub-pixel convolution below
-                k_igemm(M=P, N=oc[i], k_alg=D, A=taps_in[i], W=w.proj_w[i], **self._kdup(KD, w.proj_w[i]), bias=w.proj_b[i], flags=EP_BIAS,
+                k_igemm(M=P, N=oc[i], k_alg=D, A=taps_in[i], W=w.proj_w[i], **self._kdup(KD, w.proj_w[i], a_seg=ws.tap_seg), bias=w.proj_b[i], flags=EP_BIAS,
                         out_op=ws.tp[i], ldo_op=ocp[i], map_op=MAP_PAD, map_h=ph, map_w=pw)
                 continue
             t = ws.t0 if i == 0 else ws.t1
             rs_w, rs_b = (w.rs0_w, w.rs0_b) if i == 0 else (w.rs1_w, w.rs1_b)
-            k_igemm(M=P, N=oc[i], k_alg=D, A=taps_in[i], W=w.proj_w[i], **self._kdup(KD, w.proj_w[i]), bias=w.proj_b[i], flags=EP_BIAS, out_op=t, ldo_op=t.shape[1], split_seg=S(f"rs{i}", ocp[i]))
+            k_igemm(M=P, N=oc[i], k_alg=D, A=taps_in[i], W=w.proj_w[i], **self._kdup(KD, w.proj_w[i], a_seg=ws.tap_seg), bias=w.proj_b[i], flags=EP_BIAS, out_op=t, ldo_op=t.shape[1], split_seg=S(f"rs{i}", ocp[i]))
             k_igemm(M=P, N=s_ * s_ * oc[i], k_alg=oc[i], A=t, W=rs_w, bias=rs_b, flags=EP_BIAS, **self._kdup(t.shape[1], rs_w),
                     out_op=ws.L[i], ldo_op=ws.L[i].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=s_, shuffle_c=oc[i], split_seg=S(f"{first}{i}", ocp[i]))
-        k_igemm(M=P, N=oc[2], k_alg=D, A=taps_in[2], W=w.proj_w[2], **self._kdup(KD, w.proj_w[2]), bias=w.proj_b[2], flags=EP_BIAS,
+        k_igemm(M=P, N=oc[2], k_alg=D, A=taps_in[2], W=w.proj_w[2], **self._kdup(KD, w.proj_w[2], a_seg=ws.tap_seg), bias=w.proj_b[2], flags=EP_BIAS,
                 out_op=ws.L[2], ldo_op=ws.L[2].shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S(first + "2", ocp[2]))
-        k_igemm(M=P, N=oc[3], k_alg=D, A=taps_in[3], W=w.proj_w[3], **self._kdup(KD, w.proj_w[3]), bias=w.proj_b[3], flags=EP_BIAS,
+        k_igemm(M=P, N=oc[3], k_alg=D, A=taps_in[3], W=w.proj_w[3], **self._kdup(KD, w.proj_w[3], a_seg=ws.tap_seg), bias=w.proj_b[3], flags=EP_BIAS,
                 out_op=ws.pre3, ldo_op=ws.pre3.shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S("rs3", ocp[3]))
         self._conv3(ws.pre3, w.rs3_w, rows[3], oc[3], grid[3], stride=2, cin=oc[3], bias=w.rs3_b, flags=EP_BIAS,
                     out_op=ws.L[3], ldo_op=ws.L[3].shape[3], map_op=MAP_PAD, map_h=grid[3][0], map_w=grid[3][1], split_seg=S(first + "3", ocp[3]))

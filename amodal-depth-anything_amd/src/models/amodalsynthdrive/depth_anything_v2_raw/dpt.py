@@ -18,7 +18,7 @@ class DPTHead(_DPTHead):
         super().__init__(in_channels, features, use_bn, out_channels, use_clstoken, loss_stategy="", with_input_projection=False)
 
 
-class DepthAnythingV2(nn.Module, _EngineMixin):
+class DepthAnythingV2(_EngineMixin, nn.Module):
     def __init__(self, encoder="vitg", features=256, out_channels=(256, 512, 1024, 1024), use_bn=False, use_clstoken=False):
         super().__init__()
         self.intermediate_layer_idx = INTERMEDIATE_LAYER_IDX

@@ -118,7 +118,7 @@ def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int = 0, tail: str = "no
     if big:
         from concurrent.futures import ThreadPoolExecutor
         import os as _os
-        with ThreadPoolExecutor(max_workers=min(16, _os.cpu_count() or 1)) as ex:
+        with ThreadPoolExecutor(max_workers=min(32, _os.cpu_count() or 1)) as ex:
             list(ex.map(fill, items))
     else:
         for it in items:
@@ -167,8 +167,17 @@ def _structured_inputs(batch: int, height: int, width: int, g: torch.Generator):
 
 def make_inputs(batch: int, height: int = 518, width: int = 518, seed: int = 0, device="cpu", style: str = "noise"):
     """Synthetic inputs of SURVEY.md §8(d).  ``style="noise"``: i.i.d. uniform RGB in [0,1), rectangular amodal mask (+-1), i.i.d. uniform
-    observation in [-1,1].  ``style="structured"``: image-like inputs (_structured_inputs).  Returns (x, guide_rgb, guide_mask, observation)."""
-    assert style in ("noise", "structured"), style
+    observation in [-1,1].  ``style="structured"``: image-like inputs (_structured_inputs).  ``"zeros"`` / ``"checker"``: degenerate inputs (constant;
+    per-pixel checkerboard) -- every token equal or periodic, so operand rounding errors add coherently over positions instead of averaging out.  Returns (x, guide_rgb, guide_mask, observation)."""
+    assert style in ("noise", "structured", "zeros", "checker"), style
+    if style == "zeros":      # the all-zero image / mask / observation (a constant input: every patch token equal up to its position)
+        z = torch.zeros(batch, 3, height, width, device=device)
+        return z, z.clone(), z[:, :1].clone(), z[:, :1].clone()
+    if style == "checker":    # per-pixel 0/1 checkerboard image and mask, the complementary board as observation
+        yy, xx = torch.meshgrid(torch.arange(height), torch.arange(width), indexing="ij")
+        cb = ((yy + xx) % 2).float().to(device)
+        return (cb.expand(batch, 3, height, width).clone(), cb.expand(batch, 3, height, width).clone(), cb.expand(batch, 1, height, width).clone(),
+                (1 - cb).expand(batch, 1, height, width).clone())
     g = torch.Generator(device="cpu")
     g.manual_seed(1000003 * seed + 17)
     if style == "structured":

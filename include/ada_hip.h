@@ -355,6 +355,12 @@ int ada_normalize_fwd(const float* in, const float* minmax, int32_t batch, int64
 int ada_blend_fwd(const float* amodal, const float* base, const float* mask, int32_t batch, int32_t height,
                   int32_t width, float* out, void* stream);
 
+/* Per-image moments of a sigmoid-head depth map (output of nn.Sigmoid(), reference DA2/dpt.py:146-151): sums[(b * chunks + c) * 2 + {0, 1}] =
+ * (sum s, sum s (1 - s)) over chunk c of image b; the caller adds the chunk sums (fixed order, no atomics: bit-reproducible).  sum s(1-s) / sum s
+ * is the factor by which the sigmoid compresses the head's logit error in mean|a - b| / mean|b| for this image: hip_ext/engine.py's precision
+ * ladder re-runs the DPT head in split precision for the images where it is large (depth maps concentrated near 0).  No reference counterpart. */
+int ada_depth_stats_fwd(const float* in, int32_t batch, int64_t n_per_image, int32_t chunks, float* sums, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Tiled inference for inputs larger than the network's native 518 x 518 (the reference squashes every
  * input to 518 x 518, infer.py:17,84).  ada_tile_blend_fwd merges the per-tile predictions:

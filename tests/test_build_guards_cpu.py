@@ -1,11 +1,11 @@
-"""CPU: the build-time ISA guards (tools/isa_guard.py, run by csrc/build.py) catch what they exist for, the shipped build passes them,
+"""CPU: the build-time ISA guards (csrc/isa_guard.py, run by csrc/build.py) catch what they exist for, the shipped build passes them,
 and the generated 4-wave GEMM loop checked into csrc/ is what its generator emits."""
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "amodal-depth-anything_amd", "csrc"))
 import isa_guard as G  # noqa: E402
 
 CSRC = os.path.join(ROOT, "amodal-depth-anything_amd", "csrc")

@@ -264,6 +264,31 @@ def test_tapsum_resize_is_conv3x3_of_the_upsampled_map(hip, B, C, Cin, hi, wi, h
     assert err < (8e-3 if op == torch.bfloat16 else 1e-3)
 
 
+@pytest.mark.parametrize("wo", [17, 33, 47, 50, 65, 81, 97, 113])
+def test_tapsum_resize_right_edge_halo_column_reads_staged_data(hip, wo):
+    """Widths that are not a multiple of the 16-pixel tile: the last tile of a row starts at tx0 > 0 (patch origin px0 > 0) and its halo holds the masked column
+    X == wo.  The compute loop issues that column's LDS reads (weight 0): their offsets must stay inside the staged patch -- with a source index of 0 they
+    were (0 - px0) * PIXB < 0, bytes of another slab or of the static tables, and 0 * Inf/NaN bit patterns reached the edge pixel x = wo - 1."""
+    op = _op(hip)
+    B, C, Cin, hi, ho = 1, 64, 64, 9, 18
+    wi = (wo + 1) // 2
+    u = (_rand(B, Cin, hi, wi, seed=66) * 200.0).to(op).float()       # large tap-map values: half-precision bit patterns near the exponent top
+    w1 = _rand(C, Cin, 3, 3, seed=67) * (9 * Cin) ** -0.5
+    b1 = _rand(C, seed=68)
+    ref = F.conv2d(F.interpolate(u, size=(ho, wo), mode="bilinear", align_corners=True), w1, b1, padding=1)
+    wt = w1.permute(2, 3, 0, 1).reshape(9 * C, Cin)
+    A = u.permute(0, 2, 3, 1).reshape(-1, Cin).to(op).contiguous().to(DEV)
+    T = torch.zeros(B * hi * wi, 9 * C, dtype=torch.float32, device=DEV)
+    hip.igemm(M=B * hi * wi, N=9 * C, K=Cin, A=A, lda=Cin, W=wt.to(op).to(DEV), flags=0, out_f32=T, ldo_f32=9 * C)
+    for tdt in (torch.float32, op):
+        out = torch.full((B * ho * wo, C), float("nan"), device=DEV)
+        hip.tapsum_resize(T.to(tdt), 9 * C, B, hi, wi, ho, wo, C, b1.to(DEV), out, C)
+        got = out.view(B, ho, wo, C).permute(0, 3, 1, 2).cpu()
+        assert torch.isfinite(got).all(), f"wo={wo}: non-finite output at the right edge"
+        err = float((got[..., -2:] - ref[..., -2:]).abs().mean() / ref[..., -2:].abs().mean())
+        assert err < 3e-3, f"wo={wo} {tdt}: last two columns rel-L1 {err:.2e}"
+
+
 @pytest.mark.parametrize("G,rows,N,K,cfg,gelu", [(3, 50, 64, 128, -1, True), (5, 1369, 384, 384, -1, True), (2, 300, 256, 192, 3, False), (4, 77, 128, 64, 4, True), (7, 9, 96, 128, 1, False)])
 def test_igemm_bias_per_row_group(hip, forced_tile, G, rows, N, K, cfg, gelu):
     """ada_igemm_args.bias_row_mod: one bias vector per group of rows (the class-token read-out's per-image bias) in ONE launch."""

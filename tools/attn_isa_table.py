@@ -9,7 +9,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "amodal-depth-anything_amd", "csrc"))
 import isa_guard as G  # noqa: E402
 
 # issue cycles per instruction with two waves per SIMD (profiles/r02_a_valu_rates_ubench.txt); MFMA = pipe cycles of the instruction

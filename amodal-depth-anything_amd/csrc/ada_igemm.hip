@@ -284,9 +284,14 @@ ADA_DEV float wave_sum_dpp(float v) {
 // ran 30 % slower: fragment-shaped loads are expensive on the texture path.  profiles/r02_g_gemm_b_direct_ab.txt)
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, int LOOP = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && BM * BN == 256 * 256) ? 1 : 2) void igemm_kernel(IgemmDev p) {
-    constexpr bool PIPE4 = LOOP == 2;
-    static_assert(LOOP == 0 || LOOP == 2, "main loops: 0 single-barrier, 2 hand-scheduled 4-wave");
-    static_assert(LOOP != 2 || (BM == 256 && BN == 256 && BK == 64 && WAVES_M == 2 && WAVES_N == 2), "the hand-scheduled main loop is written for the 256x256x64 tile, 2 x 2 waves");
+    // LOOP 3 (round 5): the 4-wave loop as a PERSISTENT kernel -- one workgroup per CU walks tiles bid, bid + gridDim.x, ... of the same XCD-aware order;
+    // the LDS-DMA copies of the next tile's k-tiles 0 / 1 are issued before the epilogue of the current tile (the epilogue's transpose slabs live in
+    // the 32 KB above the two stages instead of on top of them), so the ~3.8 k-cycle prologue of a tile -- address set-up, the first slabs' trip
+    // from L2 / HBM -- runs under the previous tile's epilogue, and the workgroup launch overhead is paid once per CU instead of once per tile.
+    constexpr bool PIPE4 = LOOP >= 2;
+    constexpr bool PERSIST = LOOP == 3;
+    static_assert(LOOP == 0 || LOOP == 2 || LOOP == 3, "main loops: 0 single-barrier, 2 hand-scheduled 4-wave, 3 persistent hand-scheduled 4-wave");
+    static_assert(LOOP < 2 || (BM == 256 && BN == 256 && BK == 64 && WAVES_M == 2 && WAVES_N == 2), "the hand-scheduled main loop is written for the 256x256x64 tile, 2 x 2 waves");
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int NT = NWAVES * 64;
     constexpr int TI = BM / (WAVES_M * 32);
@@ -311,9 +316,32 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // XCD-aware (bijective) block remap: each XCD's L2 sees a contiguous run of tiles that share A panels.
+    // (persistent kernel: the walk bid, bid + gridDim.x, ... stays on one XCD because gridDim.x is a multiple of 8 or the whole problem)
     int tm, tn;
-    {
-        const int nblk = gridDim.x, bid = blockIdx.x;
+    int vb = blockIdx.x;
+    const int nblk = PERSIST ? p.tiles_m * p.tiles_n : (int)gridDim.x;
+    auto tile_of = [=](int bid, int& tm_, int& tn_) {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int gn = p.group_n;
+        const int full = p.tiles_n / gn;
+        const int per_group = p.tiles_m * gn;
+        if (logical < full * per_group) {
+            const int g = logical / per_group, rr = logical - g * per_group;
+            tm_ = rr / gn;
+            tn_ = g * gn + (rr - tm_ * gn);
+        } else {
+            const int gl = p.tiles_n - full * gn;
+            const int rr = logical - full * per_group;
+            tm_ = rr / gl;
+            tn_ = full * gn + (rr - tm_ * gl);
+        }
+    };
+    if constexpr (PERSIST) {
+        tile_of(vb, tm, tn);
+    } else {
+        const int bid = blockIdx.x;
         const int q = nblk >> 3, r = nblk & 7;
         const int xcd = bid & 7, idx = bid >> 3;
         const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -333,7 +361,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             tn = full * gn + (rr - tm * gl);
         }
     }
-    const int m0 = tm * BM, n0 = tn * BN;
+    int m0 = tm * BM, n0 = tn * BN;
     unsigned long long t_entry = 0, t_first = 0, t_loop = 0, t_vm = 0, t_bar = 0;
     if (p.dbg) t_entry = __builtin_amdgcn_s_memtime();
 
@@ -352,7 +380,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     };
     const uint32_t m_first = (uint32_t)m0 < (uint32_t)p.M ? (uint32_t)m0 : (uint32_t)p.M - 1;
     const long a_tile_el = a_row_base(m_first);                          // uniform: rows of the tile only go up from here
-    const op_t* a_tile = p.A + a_tile_el;
+    const op_t* a_tile = p.A + a_tile_el;                                // (re-pointed per tile by the persistent kernel)
     const op_t* b_tile = p.W + (long)(n0 < p.N ? n0 : p.N - 1) * p.K;
     // raw buffer resources: stride 0, 2 GiB window above the tile base (nothing relies on out-of-range behaviour), dword 3 = 0x20000
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_tile, 0, 0x7fffffff, 0x20000);
@@ -441,35 +469,58 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             if ((mask >> t) & 1u) taps_packed |= (unsigned long long)t << (4 * ntaps++);
     }
     const int nk = p.a_mode == ADA_A_PLAIN ? p.K / BK : ntaps * cps;
+    // ---- constants of the generated 4-wave loop (LOOP 2 / 3); fragments in v[0:127], accumulators in a[0:255] while it runs ----
+    [[maybe_unused]] unsigned p4_abase = 0, p4_bbase = 0, p4_m0s0 = 0, p4_period = 0x7fffffffu, p4_cnt = 0, p4_jump = 0;
+    [[maybe_unused]] long a0o = 0, b0o = 0, a1o = 0, b1o = 0, a2o = 0, b2o = 0;
+    constexpr unsigned OOB = 0x7fffffffu;     // a scalar offset beyond num_records: the copy zero-fills without fetching
+    // the asm needs the two buffer resources in SGPRs: rebuild them from readfirstlane'd pointer halves so that their uniformity is
+    // provable (the tile bases come out of float-reciprocal divisions, i.e. VALU registers -- cdna_hip_programming.md T20)
+    auto uniform_rsrc = [](const void* ptr) {
+        const unsigned long long v = (unsigned long long)ptr;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x20000);
+    };
     if constexpr (PIPE4) {
-        // everything between here and the epilogue's first dump() is the generated asm: fragments in v[0:127], accumulators in a[0:255]
         const int l15 = lane & 15, q4 = lane >> 4;
         const unsigned lds0 = (unsigned)(size_t)smem;
         const unsigned coff0 = (unsigned)((q4 ^ ((l15 >> 1) & 7)) * 16);
-        const unsigned abase = lds0 + (unsigned)((wm * 128 + l15) * RB) + coff0;
-        const unsigned bbase = lds0 + (unsigned)(A_BYTES + (wn * 128 + l15) * RB) + coff0;
-        const unsigned m0s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)wave * 1024u));
-        constexpr unsigned OOB = 0x7fffffffu;     // a scalar offset beyond num_records: the copy zero-fills without fetching
-        long a0o, b0o, a1o = 0, b1o = 0, a2o = 0, b2o = 0;
+        p4_abase = lds0 + (unsigned)((wm * 128 + l15) * RB) + coff0;
+        p4_bbase = lds0 + (unsigned)(A_BYTES + (wn * 128 + l15) * RB) + coff0;
+        p4_m0s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)wave * 1024u));
         slab_offsets(0, a0o, b0o);
         if (nk > 1) slab_offsets(1, a1o, b1o);
         if (nk > 2) slab_offsets(2, a2o, b2o);
-        unsigned period = 0x7fffffffu, cnt = 0, jump = 0;
         if (p.a_mode != ADA_A_PLAIN) {   // 3x3 conv: consecutive k-tiles of an input row (three taps) are contiguous; every 3 * cps k-tiles the
-            period = (unsigned)(3 * cps);   // A window moves down one padded input row
-            cnt = 2u % period;
-            jump = (unsigned)(((long)(p.Wp - 3) * p.lda) * 2);
+            p4_period = (unsigned)(3 * cps);   // A window moves down one padded input row
+            p4_cnt = 2u % p4_period;
+            p4_jump = (unsigned)(((long)(p.Wp - 3) * p.lda) * 2);
         }
-        // the asm needs the two buffer resources in SGPRs: rebuild them from readfirstlane'd pointer halves so that their uniformity is
-        // provable (the tile bases come out of float-reciprocal divisions, i.e. VALU registers -- cdna_hip_programming.md T20)
-        auto uniform_rsrc = [](const void* ptr) {
-            const unsigned long long v = (unsigned long long)ptr;
-            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-            return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x20000);
-        };
-        const __amdgpu_buffer_rsrc_t a_rs = uniform_rsrc(a_tile), b_rs = uniform_rsrc(b_tile);
-        pipe4_main_loop(a_rs, b_rs, a_off, b_off, abase, bbase, m0s0, (unsigned)(a0o * 2), nk > 1 ? (unsigned)(a1o * 2) : OOB, nk > 1 ? 128u : OOB,
-                        (unsigned)(a2o * 2), (unsigned)nk, period, cnt, jump);
+    }
+    // ---- persistent kernel (LOOP 3): resources of the CURRENT tile's operands + the copies of its k-tiles 0 / 1 -> stages 0 / 1 ----
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t p4_ra = uniform_rsrc(a_tile), p4_rb = uniform_rsrc(b_tile);
+    [[maybe_unused]] auto first_copies = [&](__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb) {
+        char* s0 = smem + wave * 1024;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int soa = st == 0 ? (int)(a0o * 2) : (nk > 1 ? (int)(a1o * 2) : (int)OOB);
+            const int sob = st == 0 ? 0 : (nk > 1 ? 128 : (int)OOB);
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(s0 + st * STAGE_BYTES + it * (NT * 16)), 16, (int)a_off[it], soa, 0, 0);
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(s0 + st * STAGE_BYTES + A_BYTES + it * (NT * 16)), 16, (int)b_off[it], sob, 0, 0);
+        }
+    };
+    if constexpr (PERSIST) first_copies(p4_ra, p4_rb);
+    [[maybe_unused]] bool more_tiles = false;
+    [[maybe_unused]] int vbn = 0, tm2 = 0, tn2 = 0;
+    for (;;) {   // tile loop: one trip unless PERSIST
+    if constexpr (PERSIST) {
+        pipe4_main_loop_np(p4_ra, p4_rb, a_off, b_off, p4_abase, p4_bbase, p4_m0s0, (unsigned)(a2o * 2), (unsigned)nk, p4_period, p4_cnt, p4_jump);
+    } else if constexpr (PIPE4) {
+        pipe4_main_loop(p4_ra, p4_rb, a_off, b_off, p4_abase, p4_bbase, p4_m0s0, (unsigned)(a0o * 2), nk > 1 ? (unsigned)(a1o * 2) : OOB, nk > 1 ? 128u : OOB,
+                        (unsigned)(a2o * 2), (unsigned)nk, p4_period, p4_cnt, p4_jump);
     } else {
     // Offsets of the next slab to stage.  Plain operands walk k-step j directly; a 3x3 conv walks (active tap, k-step inside the tap) with two
     // scalar counters (no division per k-step), the taps taken from taps_packed.  The walk state is passed and returned BY VALUE: captured by
@@ -565,14 +616,47 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
 
     // ---- epilogue: transpose through a wave-private LDS slab, then float4 per lane ----------------
     // The wave tile is walked in 32-row x GW-column groups (GW = 64, or 32 for the narrow tiles).
-    __syncthreads();  // every wave is done reading the last stage before the slabs overwrite it
+    __syncthreads();  // every wave is done reading the last stage before the slabs overwrite it (PERSIST: before the next tile's first slabs land in it)
     if (p.dbg) t_loop = __builtin_amdgcn_s_memtime();
+    if constexpr (PERSIST) {
+        // set-up + first copies of the NEXT tile of this workgroup: in flight under this tile's epilogue (whose slabs sit above the stages)
+        vbn = vb + (int)gridDim.x;
+        more_tiles = vbn < nblk;
+        if (more_tiles) {
+            tile_of(vbn, tm2, tn2);
+            const int m2 = tm2 * BM, n2 = tn2 * BN;
+            const uint32_t mf2 = (uint32_t)m2 < (uint32_t)p.M ? (uint32_t)m2 : (uint32_t)p.M - 1;
+            const long el2 = a_row_base(mf2);
+            a_tile = p.A + el2;
+            b_tile = p.W + (long)(n2 < p.N ? n2 : p.N - 1) * p.K;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                uint32_t m = (uint32_t)(m2 + it * ROWS_PER_PASS + srow);
+                if (m >= (uint32_t)p.M) m = (uint32_t)p.M - 1;
+                a_off[it] = (uint32_t)((a_row_base(m) - el2 + gchunk * 8) * 2);
+            }
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) {
+                int n = n2 + it * ROWS_PER_PASS + srow;
+                if (n >= p.N) n = p.N - 1;
+                b_off[it] = (uint32_t)(((long)(n - (n2 < p.N ? n2 : p.N - 1)) * p.K + gchunk * 8) * 2);
+            }
+            p4_ra = uniform_rsrc(a_tile);
+            p4_rb = uniform_rsrc(b_tile);
+            first_copies(p4_ra, p4_rb);
+        }
+    }
     constexpr int GW = TJ >= 2 ? 64 : 32;      // columns per epilogue group
     constexpr int GJ = GW / 32;                // MFMA tiles per group
     constexpr int NG = TJ / GJ;                // groups per wave-tile row block
-    constexpr int SW = GW + 4;                 // slab row stride in floats: the four 16-lane quarters of a 16x16 dump (rows 4 apart) hit disjoint banks
-    static_assert(NWAVES * 32 * SW * 4 <= 2 * STAGE_BYTES, "epilogue slabs must fit in the stage buffers");
-    float* slab = (float*)(smem + wave * (32 * SW * 4));
+    // slab row stride in floats.  Padded by 4 so that the four 16-lane quarters of a 16x16 dump (rows 4 apart) hit disjoint banks; the persistent
+    // kernel's slabs live in the 32 KB ABOVE the two stages (which hold the next tile's first k-tiles meanwhile) where there is no room for padding:
+    // rows are 64 floats and the 16-float column blocks of row r are XOR-swizzled by (r >> 2) & 3 instead -- SWZ(r) below, applied by dump and readers
+    constexpr int SW = PERSIST ? GW : GW + 4;
+    static_assert(!PERSIST || GW == 64, "persistent kernel: 64-column epilogue groups");
+    static_assert(PERSIST || NWAVES * 32 * SW * 4 <= 2 * STAGE_BYTES, "epilogue slabs must fit in the stage buffers");
+    float* slab = (float*)(smem + (PERSIST ? 2 * STAGE_BYTES : 0) + wave * (32 * SW * 4));
+#define SWZ(r) (PERSIST ? ((((r) >> 2) & 3) << 4) : 0)
     const int flags = p.flags;
     const int mbase = m0 + wm * TI * 32;
     const int nwave = n0 + wn * TJ * 32;
@@ -581,6 +665,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     // lane and sub-tile, written as two ds_write2_b32 (rows rr, rr+1) off one base address per row half a (hipcc pairs only a
     // third of the stores on its own)
     const unsigned slab_lds = (unsigned)(size_t)slab + (unsigned)((4 * (lane >> 4) * SW + (lane & 15)) * 4);
+    // persistent kernel: this lane's rows 16a + 4q + rr (q = lane >> 4) carry the swizzle key q for every a / rr: column block jb -> jb ^ q
+    unsigned slab_sw[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) slab_sw[jb] = (unsigned)(size_t)slab + (unsigned)((4 * (lane >> 4) * SW + 16 * (jb ^ (lane >> 4)) + (lane & 15)) * 4);
     auto dump = [&](int i, int g) {
 #pragma unroll
         for (int jj = 0; jj < GJ; ++jj)
@@ -596,10 +684,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 } else {
                     v = acc[i][g * GJ + jj][ab];
                 }
+                if constexpr (PERSIST) {
+                    const unsigned base = slab_sw[2 * jj + (ab & 1)] + (unsigned)((ab >> 1) * 16 * SW * 4);
+                    asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(base), "v"(v[0]), "v"(v[1]), "i"(0), "i"(SW) : "memory");
+                    asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(base), "v"(v[2]), "v"(v[3]), "i"(2 * SW), "i"(3 * SW) : "memory");
+                } else {
                 const unsigned base = slab_lds + (unsigned)((ab >> 1) * 16 * SW * 4);
                 const int col = jj * 32 + 16 * (ab & 1);   // in floats; the two offsets of ds_write2_b32 count 4-byte units (< 256)
                 asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(base), "v"(v[0]), "v"(v[1]), "i"(col), "i"(col + SW) : "memory");
                 asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(base), "v"(v[2]), "v"(v[3]), "i"(col + 2 * SW), "i"(col + 3 * SW) : "memory");
+                }
             }
     };
     static_assert((GJ - 1) * 32 + 16 + 3 * SW < 256, "ds_write2_b32 offsets are 8 bits");
@@ -626,8 +720,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 for (int k = 0; k < 4; ++k) {
                     const int row = k * 8 + rsub;
                     const int m = mbase + i * 32 + row;
-                    const float4 x1 = *(const float4*)(slab + row * SW + 4 * c8);
-                    const float4 x2 = *(const float4*)(slab + row * SW + 32 + 4 * c8);
+                    const float4 x1 = *(const float4*)(slab + row * SW + ((4 * c8) ^ SWZ(row)));
+                    const float4 x2 = *(const float4*)(slab + row * SW + ((32 + 4 * c8) ^ SWZ(row)));
                     if (m < p.M && nval) {
                         float4 gt;
                         gt.x = silu(x1.x + b1.x) * (x2.x + b2.x);
@@ -658,7 +752,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             for (int k = 0; k < 32 / RPI; ++k) {
                 const int row = k * RPI + rsub;
                 const int m = mbase + i * 32 + row;
-                const float4 v = *(const float4*)(slab + row * SW + 4 * cg);
+                const float4 v = *(const float4*)(slab + row * SW + ((4 * cg) ^ SWZ(row)));
                 float part = __builtin_fmaxf(v.x + bias4.x, 0.f) * tail4.x + __builtin_fmaxf(v.y + bias4.y, 0.f) * tail4.y +
                              __builtin_fmaxf(v.z + bias4.z, 0.f) * tail4.z + __builtin_fmaxf(v.w + bias4.w, 0.f) * tail4.w;
 #pragma unroll
@@ -712,8 +806,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
 #pragma unroll
                     for (int k = 0; k < 32 / RPI; ++k) {
                         const int row = k * RPI + rsub;
-                        float4 v0 = *(const float4*)(slab + row * SW + 8 * cg);
-                        float4 v1 = *(const float4*)(slab + row * SW + 8 * cg + 4);
+                        float4 v0 = *(const float4*)(slab + row * SW + ((8 * cg) ^ SWZ(row)));
+                        float4 v1 = *(const float4*)(slab + row * SW + ((8 * cg + 4) ^ SWZ(row)));
                         if (lnfold) {
                             v0 = ln_fold4(v0, st[k].x, st[k].y, cs0, b0);
                             v1 = ln_fold4(v1, st[k].x, st[k].y, cs1, b1);
@@ -790,7 +884,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 if (pad) walk = pad_start(p, (uint32_t)mrow);
 #pragma unroll
                 for (int k = 0; k < NKI; ++k) {
-                    float4 v = *(const float4*)(slab + (k * RPI + rsub) * SW + 4 * cg);
+                    float4 v = *(const float4*)(slab + (k * RPI + rsub) * SW + ((4 * cg) ^ SWZ(k * RPI + rsub)));
                     v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                     if constexpr (EPI == EPI_GELU) {
                         v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
@@ -866,8 +960,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 for (int k = 0; k < 32 / RPI; ++k) {
                     const int row = k * RPI + rsub;
                     const int m = mbase + i * 32 + row;
-                    float4 v0 = *(const float4*)(slab + row * SW + 8 * cg);
-                    float4 v1 = *(const float4*)(slab + row * SW + 8 * cg + 4);
+                    float4 v0 = *(const float4*)(slab + row * SW + ((8 * cg) ^ SWZ(row)));
+                    float4 v1 = *(const float4*)(slab + row * SW + ((8 * cg + 4) ^ SWZ(row)));
                     if (p.bias_row_mod > 0) {   // one bias vector per group of rows (the class-token read-out: a per-image bias, DA2/dpt.py:164-167)
                         uint32_t grp, rr_;
                         fast_divmod((uint32_t)(m < p.M ? m : p.M - 1), p.dBiasMod, grp, rr_);
@@ -980,7 +1074,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             for (int k = 0; k < NKI; ++k) {
                 const int row = k * RPI + rsub;
                 const int m = mbase + i * 32 + row;
-                float4 v = *(const float4*)(slab + row * SW + 4 * cg);
+                float4 v = *(const float4*)(slab + row * SW + ((4 * cg) ^ SWZ(row)));
                 v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                 if constexpr (EPI == EPI_GELU) {
                     v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
@@ -1028,6 +1122,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             }
         }
     }
+    if constexpr (PERSIST) {
+        if (!more_tiles) break;
+        vb = vbn; tm = tm2; tn = tn2;
+        m0 = tm * BM; n0 = tn * BN;
+    } else {
+        break;
+    }
+    }   // tile loop
     // ---- LayerNorm tail (ada_igemm_args.ln_out): the LayerNorm that follows proj / fc2 (reference block.py:84,87) reads exactly the rows this
     //      launch has just written to the fp32 residual stream.  Every tile publishes its part of the row panel (write-through stores above, the
     //      wave's stores drained, one ticket per tile on the panel's counter); the tile that draws the last ticket normalises the panel's rows
@@ -1133,13 +1235,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     }
 }
 
+#undef SWZ
 static std::atomic<int> g_group_override{0};  // debug: force the column-group width (0 = model)
 static thread_local int g_last_tile = -1;   // tile configuration of the calling thread's most recent launch (ada_debug_last_tile)
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, int LOOP = 0>
 int launch_cfg(IgemmDev& d, hipStream_t stream) {
     constexpr int NT = WAVES_M * WAVES_N * 64;
-    constexpr int SMEM = 2 * (BM + BN) * BK * 2;
+    constexpr int SMEM = 2 * (BM + BN) * BK * 2 + (LOOP == 3 ? 32 * 1024 : 0);   // persistent kernel: + the epilogue slabs above the stages (160 KB in all)
     d.tiles_m = (d.M + BM - 1) / BM;
     d.tiles_n = (d.N + BN - 1) / BN;
     {
@@ -1167,7 +1270,8 @@ int launch_cfg(IgemmDev& d, hipStream_t stream) {
         }
     });
     g_last_tile = (BM == 256 && BN == 32 ? 0 : BM == 128 && BN == 64 ? 1 : BM == 256 && BN == 128 ? 2 : BM == 256 && BN == 256 ? 3 : 4) + 100 * LOOP;
-    const long nblk = (long)d.tiles_m * d.tiles_n;
+    long nblk = (long)d.tiles_m * d.tiles_n;
+    if (LOOP == 3 && nblk > 256) nblk = 256;    // persistent: one workgroup per CU (a multiple of 8, so a workgroup's tile walk stays on its XCD)
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), SMEM, stream, d);
     return ada_check_launch("ada_igemm");
 }
@@ -1187,6 +1291,20 @@ static inline double tile_time(long M, long N, int bm, int bn, int occ, double e
 // 4-wave loop where its main loop outweighs its slower prologue / epilogue (measured: k-loops of >= 128 k-tiles)
 // (its scalar A-offset counters assume a monotonic walk: a split operand, whose third k segment re-reads the first, stays on the 8-wave loop)
 static inline bool use_pipe4(const IgemmDev& d) { return d.a_dup_seg == 0 && d.a_wrap == 0 && d.tap_cols == 0 && d.ln_out == nullptr && (d.variant >= 16 || (d.variant == 0 && d.K >= 8192)); }
+// ... and its persistent form (variant 32 forces it wherever the 4-wave loop applies; ADA_PERSIST_MIN_TILES / _MAX_K tune the default choice)
+static std::atomic<int> g_persist_min_tiles{-1}, g_persist_min_k{0};
+static inline bool use_persist(const IgemmDev& d, long tiles) {
+    if (d.variant >= 32) return true;
+    if (d.variant != 0) return false;
+    const int mt = g_persist_min_tiles.load(std::memory_order_relaxed);
+    return mt >= 0 && tiles >= mt && d.K >= g_persist_min_k.load(std::memory_order_relaxed);
+}
+static inline bool want_pipe4(const IgemmDev& d) {   // the 4-wave loop in either form
+    if (use_pipe4(d)) return true;
+    if (d.a_dup_seg != 0 || d.a_wrap != 0 || d.tap_cols != 0 || d.ln_out != nullptr || d.variant != 0) return false;
+    const long tiles = (long)((d.M + 255) / 256) * ((d.N + 255) / 256);
+    return use_persist(d, tiles);
+}
 
 template <int EPI>
 int launch_epi(IgemmDev& d, hipStream_t s, int force) {
@@ -1214,7 +1332,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force) {
     if ((d.flags & ADA_EP_ROWSTATS) && cfg == 0) cfg = 1;
     if constexpr (EPI == EPI_SWIGLU) {
         if (cfg == 4 || cfg == 2) return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
-        if (use_pipe4(d)) return launch_cfg<256, 256, 64, 2, 2, EPI, 2>(d, s);
+        if (want_pipe4(d)) return use_persist(d, (long)((d.M + 255) / 256) * ((d.N + 255) / 256)) ? launch_cfg<256, 256, 64, 2, 2, EPI, 3>(d, s) : launch_cfg<256, 256, 64, 2, 2, EPI, 2>(d, s);
         return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
     } else if constexpr (EPI == EPI_TAIL) {
         return cfg == 0 ? launch_cfg<256, 32, 64, 4, 1, EPI>(d, s) : launch_cfg<128, 64, 64, 4, 1, EPI>(d, s);
@@ -1225,7 +1343,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force) {
             case 2: return launch_cfg<256, 128, 64, 4, 2, EPI>(d, s);
             case 4: return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
             default:
-                if (use_pipe4(d)) return launch_cfg<256, 256, 64, 2, 2, EPI, 2>(d, s);
+                if (want_pipe4(d)) return use_persist(d, (long)((d.M + 255) / 256) * ((d.N + 255) / 256)) ? launch_cfg<256, 256, 64, 2, 2, EPI, 3>(d, s) : launch_cfg<256, 256, 64, 2, 2, EPI, 2>(d, s);
                 return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
         }
     }
@@ -1236,7 +1354,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force) {
 // ---- tuning / diagnostic hooks (declared in include/ada_hip.h; process-global atomics, not needed for correct operation) ----
 static std::atomic<unsigned long long*> g_dbg{nullptr};
 static std::atomic<int> g_force_tile{-1};
-static std::atomic<int> g_variant{0};   // main loop of the 256x256 tile -- 0: by shape (default); 4: single-barrier 8-wave loop; 16: hand-scheduled 4-wave loop
+static std::atomic<int> g_variant{0};   // main loop of the 256x256 tile -- 0: by shape (default); 4: single-barrier 8-wave loop; 16: hand-scheduled 4-wave loop; 32: its persistent form
 static std::once_flag g_env_once;
 // A/B switches for kernel experiments: the environment (ADA_IGEMM_TILE / _GROUP / _VARIANT) presets the hooks below ONCE per process, and it
 // does so before the first explicit ada_debug_set_* call as well as before the first launch -- an explicit call always has the last word
@@ -1247,13 +1365,15 @@ static void apply_env_presets() {
         if (const char* gr = getenv("ADA_IGEMM_GROUP")) g_group_override.store(atoi(gr), std::memory_order_relaxed);
         if (const char* va = getenv("ADA_IGEMM_VARIANT")) {
             const int v = atoi(va);
-            g_variant.store(v >= 16 ? 16 : v >= 4 ? 4 : 0, std::memory_order_relaxed);
+            g_variant.store(v >= 32 ? 32 : v >= 16 ? 16 : v >= 4 ? 4 : 0, std::memory_order_relaxed);
         }
+        if (const char* pm = getenv("ADA_PERSIST_MIN_TILES")) g_persist_min_tiles.store(atoi(pm), std::memory_order_relaxed);
+        if (const char* pk = getenv("ADA_PERSIST_MIN_K")) g_persist_min_k.store(atoi(pk), std::memory_order_relaxed);
     });
 }
 // debug hook (not part of the stable ABI): override the tile configuration (-1 = heuristic)
 extern "C" void ada_debug_set_tile(int cfg) { apply_env_presets(); g_force_tile.store(cfg, std::memory_order_relaxed); }
-extern "C" void ada_debug_set_variant(int v) { apply_env_presets(); g_variant.store(v >= 16 ? 16 : v >= 4 ? 4 : 0, std::memory_order_relaxed); }
+extern "C" void ada_debug_set_variant(int v) { apply_env_presets(); g_variant.store(v >= 32 ? 32 : v >= 16 ? 16 : v >= 4 ? 4 : 0, std::memory_order_relaxed); }
 extern "C" void ada_debug_set_group(int g) { apply_env_presets(); g_group_override.store(g, std::memory_order_relaxed); }
 extern "C" int ada_debug_last_tile(void) { return g_last_tile; }
 // debug hook (not part of the stable ABI): device buffer of 8 x u64 per workgroup, or NULL to disable

@@ -157,16 +157,31 @@ def check_packed_f32(body):
     return [(no, ins) for no, ins in body if re.match(r"v_pk_\w+_f32\b", ins)]
 
 
-def check_agpr_after_loop(body, end_marker="LPIPE4_END"):
-    """Instructions after the generated loop's end label that touch an AGPR other than by v_accvgpr_read."""
-    start = None
-    for idx, (no, ins) in enumerate(body):
-        if end_marker in ins and LABEL.match(ins):
-            start = idx
-    if start is None:
+def check_agpr_after_loop(body, end_marker="LPIPE4_END", begin_marker="LPIPE4_BEGIN"):
+    """Instructions OUTSIDE the generated loop that touch an AGPR other than by v_accvgpr_read.  The generated asm brackets itself with the labels
+    LPIPE4_BEGIN_<n> / LPIPE4_END_<n>; everything outside those brackets is compiler-generated code that knows the AGPRs only as clobbered while the
+    epilogue's dumps fetch the accumulators from them -- and in the persistent kernel (a tile loop around loop + epilogue) the code textually BEFORE
+    the asm runs after it as well.  Listings without a begin label (older form): everything after the last end label."""
+    begins = [idx for idx, (no, ins) in enumerate(body) if begin_marker in ins and LABEL.match(ins)]
+    ends = [idx for idx, (no, ins) in enumerate(body) if end_marker in ins and LABEL.match(ins)]
+    if not ends:
         return None
     bad = []
-    for no, ins in body[start + 1:]:
+    if begins:
+        inside = False
+        for no, ins in body:
+            if LABEL.match(ins):
+                if begin_marker in ins:
+                    inside = True
+                elif end_marker in ins:
+                    inside = False
+                continue
+            if inside or not _regs(ins, AREG):
+                continue
+            if not ins.startswith("v_accvgpr_read"):
+                bad.append((no, ins))
+        return bad
+    for no, ins in body[ends[-1] + 1:]:
         if LABEL.match(ins) or not _regs(ins, AREG):
             continue
         if not ins.startswith("v_accvgpr_read"):

@@ -70,24 +70,32 @@ def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int = 0, tail: str = "no
         g = _gen(key, seed)
         shape = tuple(t.shape)
         leaf = key.rsplit(".", 1)[-1]
+        # Draw straight into the destination where it is a contiguous fp32 tensor (torch.randn(shape, generator=g) IS empty(shape).normal_(generator=g):
+        # same stream, same values) and scale in place: one pass over memory instead of three temporaries -- the ViT-G fill is 4.4 GB and its cost
+        # is memory traffic and page faults, not the generator.  Every in-place sequence below performs the same fp32 operations in the same order
+        # as the expression it replaces (x * a then + b), so the values are bit-identical (tests/test_synth_weights_cpu.py pins them).
+        inplace = t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad
+        v = t if inplace else torch.empty(shape, dtype=torch.float32)
 
-        def randn(*s):
-            return torch.randn(*s, generator=g, dtype=torch.float32)
+        def randn_():
+            return v.normal_(generator=g)
+
+        def rand_():
+            return v.uniform_(generator=g)
 
         if leaf == "running_var":      # BatchNorm2d statistics (use_bn=True heads): strictly positive
-            v = 0.5 + torch.rand(*shape, generator=g, dtype=torch.float32)
+            rand_().add_(0.5)
         elif leaf == "running_mean":
-            v = 0.2 * randn(*shape)
-        elif ".bn1." in key or ".bn2." in key:
-            v = 1.0 + 0.1 * randn(*shape) if leaf == "weight" else 0.1 * randn(*shape)
-        elif _is_norm_key(key):
-            v = 1.0 + 0.1 * randn(*shape) if leaf == "weight" else 0.1 * randn(*shape)
+            randn_().mul_(0.2)
+        elif ".bn1." in key or ".bn2." in key or _is_norm_key(key):
+            if leaf == "weight":
+                randn_().mul_(0.1).add_(1.0)
+            else:
+                randn_().mul_(0.1)
         elif leaf == "gamma":  # LayerScale
-            v = 0.3 + 0.7 * torch.rand(*shape, generator=g, dtype=torch.float32)
-        elif leaf == "cls_token" or leaf == "mask_token":
-            v = 0.5 * randn(*shape)
-        elif leaf == "pos_embed":
-            v = 0.5 * randn(*shape)
+            rand_().mul_(0.7).add_(0.3)
+        elif leaf in ("cls_token", "mask_token", "pos_embed"):
+            randn_().mul_(0.5)
         elif t.ndim >= 2:
             if "resize_layers.0" in key or "resize_layers.1" in key:
                 fan_in = shape[0]  # ConvTranspose2d [Cin, Cout, k, k], stride == k: Cin terms per output
@@ -98,18 +106,19 @@ def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int = 0, tail: str = "no
             gain = 1.0
             if "patch_embed_guidance" in key:
                 gain = 2.0
-            v = randn(*shape)
+            randn_()
             if "output_conv2.2" in key:
                 # final 1x1 conv sees post-ReLU (all-positive) features: a zero-mean filter keeps the
                 # logits centred so the sigmoid output spans (0,1) instead of saturating at one end.
-                v = v - v.mean()
+                v.sub_(v.mean())
                 gain = 3.0
-            v = v * (gain / fan_in ** 0.5)
+            v.mul_(gain / fan_in ** 0.5)
         else:  # biases
-            v = 0.1 * randn(*shape)
+            randn_().mul_(0.1)
         if tail == "heavy":
-            v = _apply_outliers_(key, v)
-        t.copy_(v.to(t.dtype))
+            _apply_outliers_(key, v)
+        if not inplace:
+            t.copy_(v.to(t.dtype))
 
     # every tensor has its own generator, so the keys can be filled concurrently (torch releases the GIL inside randn): the ViT-G fixtures
     # (1.1 G parameters) spend most of their test time here

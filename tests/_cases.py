@@ -1,8 +1,11 @@
 """Shared helpers: rebuild the synthetic weights / inputs of a golden fixture and the product model."""
 import contextlib
 import json
+import atexit
 import os
+import threading
 from collections import OrderedDict
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -23,20 +26,41 @@ def load_golden(name):
     return torch.from_numpy(z["out"]), json.loads(str(z["meta"]))
 
 
+_INIT_NAMES = ("kaiming_uniform_", "kaiming_normal_", "trunc_normal_", "normal_", "uniform_", "xavier_uniform_")
+_SKIP_THREADS = set()      # idents of the threads that are constructing a model whose parameters will all be overwritten
+_INIT_LOCK = threading.Lock()
+_INIT_PATCHED = False
+
+
+def _install_init_patch():
+    """torch.nn.init's random initialisers become per-thread switchable (installed once): a thread inside _skip_random_init() gets no-ops, every
+    other thread -- a test that constructs a module and relies on its default initialisation -- gets the real functions.  (Models are also built by
+    the background threads of fixture_model, so a plain save / restore of the module attributes would race.)"""
+    global _INIT_PATCHED
+    with _INIT_LOCK:
+        if _INIT_PATCHED:
+            return
+        init = torch.nn.init
+        for n in _INIT_NAMES:
+            def wrapper(tensor, *a, _orig=getattr(init, n), **k):
+                if threading.get_ident() in _SKIP_THREADS:
+                    return tensor
+                return _orig(tensor, *a, **k)
+            setattr(init, n, wrapper)
+        _INIT_PATCHED = True
+
+
 @contextlib.contextmanager
 def _skip_random_init():
-    """Every caller overwrites all parameters with load_state_dict(strict=True) right after construction: the random initialisers of
-    nn.Linear / nn.Conv2d / trunc_normal_ are 1.1 G draws for ViT-G (seconds per test) that nothing reads."""
-    init = torch.nn.init
-    names = ("kaiming_uniform_", "kaiming_normal_", "trunc_normal_", "normal_", "uniform_", "xavier_uniform_")
-    saved = {n: getattr(init, n) for n in names}
+    """Every caller overwrites all parameters right after construction: the random initialisers of nn.Linear / nn.Conv2d / trunc_normal_ are
+    1.1 G draws for ViT-G (seconds per test) that nothing reads."""
+    _install_init_patch()
+    me = threading.get_ident()
+    _SKIP_THREADS.add(me)
     try:
-        for n in names:
-            setattr(init, n, lambda tensor, *a, **k: tensor)
         yield
     finally:
-        for n, f in saved.items():
-            setattr(init, n, f)
+        _SKIP_THREADS.discard(me)
 
 
 def build_product_model(case):
@@ -112,19 +136,50 @@ def golden_names_by_model():
 
 _MODEL_CACHE = OrderedDict()      # weights_key -> product model on the GPU (parameters = the fixture's fill, final bias set per fixture)
 _MODEL_CACHE_BYTES = 14 << 30
+_PREFETCH = {}                    # weights_key -> Future of the filled CPU model (built by a background thread while earlier fixtures run on the GPU)
+_PREFETCH_AHEAD = 2
+_POOL = None
+_KEY_ORDER = None                 # distinct weights_keys in the order golden_names_by_model() visits them, with one case per key
+
+
+def _filled_cpu_model(case):
+    """Product model on the CPU with the fixture's synthetic fill drawn IN PLACE into its parameters (state_dict() hands out the parameters' own
+    storage): no cloned state_dict, no load_state_dict copy -- for ViT-G that is 2 x 4.4 GB of memory traffic and page faults per fixture."""
+    model = build_product_model(case)
+    _fill(model.state_dict(), case, None)
+    return model
+
+
+def _submit_prefetch(key):
+    global _POOL, _KEY_ORDER
+    if _KEY_ORDER is None:
+        _KEY_ORDER = OrderedDict()
+        for n in golden_names_by_model():
+            c = load_golden(n)[1]["case"]
+            _KEY_ORDER.setdefault(weights_key(c), c)
+    keys = list(_KEY_ORDER)
+    if key not in _KEY_ORDER:
+        return
+    if _POOL is None:
+        _POOL = ThreadPoolExecutor(max_workers=_PREFETCH_AHEAD, thread_name_prefix="fixture-fill")
+        atexit.register(lambda: _POOL.shutdown(wait=False, cancel_futures=True))
+    i = keys.index(key)
+    for k in keys[i + 1:i + 1 + _PREFETCH_AHEAD]:
+        if k not in _MODEL_CACHE and k not in _PREFETCH:
+            _PREFETCH[k] = _POOL.submit(_filled_cpu_model, _KEY_ORDER[k])
 
 
 def fixture_model(meta):
     """The product model of a fixture, on the GPU, built once per weights_key for the session: only the logit-centring final bias differs
-    between the fixtures of one key, and that is one scalar written in place (the engine re-packs on the parameter's version bump).
+    between the fixtures of one key, and that is one scalar written in place (the engine re-packs on the parameter's version bump).  While a
+    model's fixtures run, background threads draw the fills of the next keys in the suite's order (the CPU work the suite used to wait for).
     Callers must not change the model's policy attributes (head_precision, ...) -- tests that do build their own."""
     case = meta["case"]
     key = weights_key(case)
     model = _MODEL_CACHE.get(key)
     if model is None:
-        model = build_product_model(case)
-        model.load_state_dict(synth_state_dict(model, meta), strict=True)
-        model = model.cuda()
+        fut = _PREFETCH.pop(key, None)
+        model = (fut.result() if fut is not None else _filled_cpu_model(case)).cuda()
         _MODEL_CACHE[key] = model
         size = lambda m: sum(p.numel() * p.element_size() for p in m.parameters())   # noqa: E731
         while len(_MODEL_CACHE) > 1 and sum(size(m) for m in _MODEL_CACHE.values()) > _MODEL_CACHE_BYTES:
@@ -132,6 +187,7 @@ def fixture_model(meta):
             torch.cuda.empty_cache()
     else:
         _MODEL_CACHE.move_to_end(key)
+    _submit_prefetch(key)
     with torch.no_grad():
         dict(model.named_parameters())[meta["final_bias_key"]].fill_(meta["final_bias"])
     return model

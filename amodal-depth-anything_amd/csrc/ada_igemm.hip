@@ -514,7 +514,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     };
     if constexpr (PERSIST) first_copies(p4_ra, p4_rb);
     [[maybe_unused]] bool more_tiles = false;
-    [[maybe_unused]] int vbn = 0, tm2 = 0, tn2 = 0;
+    [[maybe_unused]] int vbn = 0;
     for (;;) {   // tile loop: one trip unless PERSIST
     if constexpr (PERSIST) {
         pipe4_main_loop_np(p4_ra, p4_rb, a_off, b_off, p4_abase, p4_bbase, p4_m0s0, (unsigned)(a2o * 2), (unsigned)nk, p4_period, p4_cnt, p4_jump);
@@ -618,34 +618,54 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     // The wave tile is walked in 32-row x GW-column groups (GW = 64, or 32 for the narrow tiles).
     __syncthreads();  // every wave is done reading the last stage before the slabs overwrite it (PERSIST: before the next tile's first slabs land in it)
     if (p.dbg) t_loop = __builtin_amdgcn_s_memtime();
+    // Persistent kernel: set-up + first copies of the NEXT tile of this workgroup, in flight under this tile's epilogue (whose slabs sit above the stages).
+    // The per-lane copy offsets are computed HERE for the copies and AGAIN behind the epilogue for the main loop (~150 VALU operations per tile):
+    // carried through the epilogue they -- and what the compiler derives from them ahead of time -- cost ~60 VGPRs that the epilogue does not have
+    // (the generated loop owns v0-v135 and every AGPR).
+    auto restage = [&](int vb_next) {
+        int tm_, tn_;
+        tile_of(vb_next, tm_, tn_);
+        int srow_ = srow, gchunk_ = gchunk;
+        asm volatile("" : "+v"(srow_), "+v"(gchunk_));      // laundered: their products with lda / K are loop-invariant 64-bit VGPR pairs otherwise
+        const int m2 = tm_ * BM, n2 = tn_ * BN;
+        const uint32_t mf2 = (uint32_t)m2 < (uint32_t)p.M ? (uint32_t)m2 : (uint32_t)p.M - 1;
+        const long el2 = a_row_base(mf2);
+        a_tile = p.A + el2;
+        b_tile = p.W + (long)(n2 < p.N ? n2 : p.N - 1) * p.K;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            uint32_t m = (uint32_t)(m2 + it * ROWS_PER_PASS + srow_);
+            if (m >= (uint32_t)p.M) m = (uint32_t)p.M - 1;
+            a_off[it] = (uint32_t)((a_row_base(m) - el2 + gchunk_ * 8) * 2);
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            int n = n2 + it * ROWS_PER_PASS + srow_;
+            if (n >= p.N) n = p.N - 1;
+            b_off[it] = (uint32_t)(((long)(n - (n2 < p.N ? n2 : p.N - 1)) * p.K + gchunk_ * 8) * 2);
+        }
+        p4_ra = uniform_rsrc(a_tile);
+        p4_rb = uniform_rsrc(b_tile);
+    };
     if constexpr (PERSIST) {
-        // set-up + first copies of the NEXT tile of this workgroup: in flight under this tile's epilogue (whose slabs sit above the stages)
         vbn = vb + (int)gridDim.x;
         more_tiles = vbn < nblk;
         if (more_tiles) {
-            tile_of(vbn, tm2, tn2);
-            const int m2 = tm2 * BM, n2 = tn2 * BN;
-            const uint32_t mf2 = (uint32_t)m2 < (uint32_t)p.M ? (uint32_t)m2 : (uint32_t)p.M - 1;
-            const long el2 = a_row_base(mf2);
-            a_tile = p.A + el2;
-            b_tile = p.W + (long)(n2 < p.N ? n2 : p.N - 1) * p.K;
-#pragma unroll
-            for (int it = 0; it < A_IT; ++it) {
-                uint32_t m = (uint32_t)(m2 + it * ROWS_PER_PASS + srow);
-                if (m >= (uint32_t)p.M) m = (uint32_t)p.M - 1;
-                a_off[it] = (uint32_t)((a_row_base(m) - el2 + gchunk * 8) * 2);
-            }
-#pragma unroll
-            for (int it = 0; it < B_IT; ++it) {
-                int n = n2 + it * ROWS_PER_PASS + srow;
-                if (n >= p.N) n = p.N - 1;
-                b_off[it] = (uint32_t)(((long)(n - (n2 < p.N ? n2 : p.N - 1)) * p.K + gchunk * 8) * 2);
-            }
-            p4_ra = uniform_rsrc(a_tile);
-            p4_rb = uniform_rsrc(b_tile);
+            restage(vbn);
             first_copies(p4_ra, p4_rb);
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) asm volatile("" ::"v"(a_off[it]));     // consumed: nothing of this set-up lives on through the epilogue
         }
     }
+    // Persistent kernel: the epilogue sits inside the tile loop, and everything it derives from the lane index (slab addresses, row / column
+    // group of the lane, pad-walk starts) is loop-invariant -- hoisted, it would have to stay in VGPRs across the generated main loop, which owns
+    // v0-v135 (measured: 50 spilled VGPRs).  The lane index is laundered once per tile so that those values are recomputed (a few dozen VALU ops).
+    int lane_l_ = lane;
+    if constexpr (PERSIST) asm volatile("" : "+v"(lane_l_));
+    const int lane = lane_l_;      // shadows the kernel-scope lane for the rest of the tile
+    float zf_ = 0.0f;              // ... and so is the zero the residual registers start from (32 hoisted zero VGPRs otherwise)
+    if constexpr (PERSIST) asm volatile("" : "+v"(zf_));
+    const float zf = zf_;
     constexpr int GW = TJ >= 2 ? 64 : 32;      // columns per epilogue group
     constexpr int GJ = GW / 32;                // MFMA tiles per group
     constexpr int NG = TJ / GJ;                // groups per wave-tile row block
@@ -851,7 +871,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             constexpr bool AHEAD = (NWAVES == 8 && TJ <= 2) || PIPE4;
             float4 rcur[NKI], rnext[AHEAD ? NKI : 1];
 #pragma unroll
-            for (int k = 0; k < NKI; ++k) rcur[k] = make_float4(0, 0, 0, 0);
+            for (int k = 0; k < NKI; ++k) rcur[k] = make_float4(zf, zf, zf, zf);
             if (AHEAD && has_res) {
                 const float* r0 = rptr(0);
 #pragma unroll
@@ -1038,7 +1058,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
         constexpr bool AHEAD = (NWAVES == 8 && TJ <= 2) || PIPE4;
         float4 rcur[NKI], rnext[AHEAD ? NKI : 1];
 #pragma unroll
-        for (int k = 0; k < NKI; ++k) rcur[k] = make_float4(0, 0, 0, 0);
+        for (int k = 0; k < NKI; ++k) rcur[k] = make_float4(zf, zf, zf, zf);
         if (AHEAD && has_res) {
 #pragma unroll
             for (int k = 0; k < NKI; ++k) rcur[k] = *(const float4*)res_ptr(0, k);
@@ -1124,7 +1144,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     }
     if constexpr (PERSIST) {
         if (!more_tiles) break;
-        vb = vbn; tm = tm2; tn = tn2;
+        vb = vbn;
+        restage(vb);                 // again: the copy offsets / resources the main loop of the next tile walks (see above)
+        tile_of(vb, tm, tn);
         m0 = tm * BM; n0 = tn * BN;
     } else {
         break;
@@ -1237,6 +1259,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
 
 #undef SWZ
 static std::atomic<int> g_group_override{0};  // debug: force the column-group width (0 = model)
+static std::atomic<int> g_persist_grid{0};    // debug: workgroups of the persistent kernel (0 = one per CU)
 static thread_local int g_last_tile = -1;   // tile configuration of the calling thread's most recent launch (ada_debug_last_tile)
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, int LOOP = 0>
@@ -1271,7 +1294,10 @@ int launch_cfg(IgemmDev& d, hipStream_t stream) {
     });
     g_last_tile = (BM == 256 && BN == 32 ? 0 : BM == 128 && BN == 64 ? 1 : BM == 256 && BN == 128 ? 2 : BM == 256 && BN == 256 ? 3 : 4) + 100 * LOOP;
     long nblk = (long)d.tiles_m * d.tiles_n;
-    if (LOOP == 3 && nblk > 256) nblk = 256;    // persistent: one workgroup per CU (a multiple of 8, so a workgroup's tile walk stays on its XCD)
+    if (LOOP == 3) {   // persistent: one workgroup per CU (a multiple of 8, so a workgroup's tile walk stays on its XCD); the debug hook shrinks the grid
+        const int cap = g_persist_grid.load(std::memory_order_relaxed);      // so that small test problems walk several tiles per workgroup
+        if (nblk > (cap > 0 ? cap : 256)) nblk = cap > 0 ? cap : 256;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), SMEM, stream, d);
     return ada_check_launch("ada_igemm");
 }
@@ -1375,6 +1401,7 @@ static void apply_env_presets() {
 extern "C" void ada_debug_set_tile(int cfg) { apply_env_presets(); g_force_tile.store(cfg, std::memory_order_relaxed); }
 extern "C" void ada_debug_set_variant(int v) { apply_env_presets(); g_variant.store(v >= 32 ? 32 : v >= 16 ? 16 : v >= 4 ? 4 : 0, std::memory_order_relaxed); }
 extern "C" void ada_debug_set_group(int g) { apply_env_presets(); g_group_override.store(g, std::memory_order_relaxed); }
+extern "C" void ada_debug_set_persist_grid(int n) { apply_env_presets(); g_persist_grid.store(n > 0 ? n : 0, std::memory_order_relaxed); }
 extern "C" int ada_debug_last_tile(void) { return g_last_tile; }
 // debug hook (not part of the stable ABI): device buffer of 8 x u64 per workgroup, or NULL to disable
 extern "C" void ada_debug_set_timestamps(void* dev_buf) { g_dbg.store((unsigned long long*)dev_buf, std::memory_order_relaxed); }

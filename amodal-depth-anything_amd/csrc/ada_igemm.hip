@@ -284,14 +284,9 @@ ADA_DEV float wave_sum_dpp(float v) {
 // ran 30 % slower: fragment-shaped loads are expensive on the texture path.  profiles/r02_g_gemm_b_direct_ab.txt)
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, int LOOP = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && BM * BN == 256 * 256) ? 1 : 2) void igemm_kernel(IgemmDev p) {
-    // LOOP 3 (round 5): the 4-wave loop as a PERSISTENT kernel -- one workgroup per CU walks tiles bid, bid + gridDim.x, ... of the same XCD-aware order;
-    // the LDS-DMA copies of the next tile's k-tiles 0 / 1 are issued before the epilogue of the current tile (the epilogue's transpose slabs live in
-    // the 32 KB above the two stages instead of on top of them), so the ~3.8 k-cycle prologue of a tile -- address set-up, the first slabs' trip
-    // from L2 / HBM -- runs under the previous tile's epilogue, and the workgroup launch overhead is paid once per CU instead of once per tile.
-    constexpr bool PIPE4 = LOOP >= 2;
-    constexpr bool PERSIST = LOOP == 3;
-    static_assert(LOOP == 0 || LOOP == 2 || LOOP == 3, "main loops: 0 single-barrier, 2 hand-scheduled 4-wave, 3 persistent hand-scheduled 4-wave");
-    static_assert(LOOP < 2 || (BM == 256 && BN == 256 && BK == 64 && WAVES_M == 2 && WAVES_N == 2), "the hand-scheduled main loop is written for the 256x256x64 tile, 2 x 2 waves");
+    constexpr bool PIPE4 = LOOP == 2;
+    static_assert(LOOP == 0 || LOOP == 2, "main loops: 0 single-barrier, 2 hand-scheduled 4-wave");
+    static_assert(LOOP != 2 || (BM == 256 && BN == 256 && BK == 64 && WAVES_M == 2 && WAVES_N == 2), "the hand-scheduled main loop is written for the 256x256x64 tile, 2 x 2 waves");
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int NT = NWAVES * 64;
     constexpr int TI = BM / (WAVES_M * 32);
@@ -316,32 +311,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // XCD-aware (bijective) block remap: each XCD's L2 sees a contiguous run of tiles that share A panels.
-    // (persistent kernel: the walk bid, bid + gridDim.x, ... stays on one XCD because gridDim.x is a multiple of 8 or the whole problem)
     int tm, tn;
-    int vb = blockIdx.x;
-    const int nblk = PERSIST ? p.tiles_m * p.tiles_n : (int)gridDim.x;
-    auto tile_of = [=](int bid, int& tm_, int& tn_) {
-        const int q = nblk >> 3, r = nblk & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        const int gn = p.group_n;
-        const int full = p.tiles_n / gn;
-        const int per_group = p.tiles_m * gn;
-        if (logical < full * per_group) {
-            const int g = logical / per_group, rr = logical - g * per_group;
-            tm_ = rr / gn;
-            tn_ = g * gn + (rr - tm_ * gn);
-        } else {
-            const int gl = p.tiles_n - full * gn;
-            const int rr = logical - full * per_group;
-            tm_ = rr / gl;
-            tn_ = full * gn + (rr - tm_ * gl);
-        }
-    };
-    if constexpr (PERSIST) {
-        tile_of(vb, tm, tn);
-    } else {
-        const int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
         const int q = nblk >> 3, r = nblk & 7;
         const int xcd = bid & 7, idx = bid >> 3;
         const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -361,7 +333,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             tn = full * gn + (rr - tm * gl);
         }
     }
-    int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BN;
     unsigned long long t_entry = 0, t_first = 0, t_loop = 0, t_vm = 0, t_bar = 0;
     if (p.dbg) t_entry = __builtin_amdgcn_s_memtime();
 
@@ -380,7 +352,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     };
     const uint32_t m_first = (uint32_t)m0 < (uint32_t)p.M ? (uint32_t)m0 : (uint32_t)p.M - 1;
     const long a_tile_el = a_row_base(m_first);                          // uniform: rows of the tile only go up from here
-    const op_t* a_tile = p.A + a_tile_el;                                // (re-pointed per tile by the persistent kernel)
+    const op_t* a_tile = p.A + a_tile_el;
     const op_t* b_tile = p.W + (long)(n0 < p.N ? n0 : p.N - 1) * p.K;
     // raw buffer resources: stride 0, 2 GiB window above the tile base (nothing relies on out-of-range behaviour), dword 3 = 0x20000
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_tile, 0, 0x7fffffff, 0x20000);
@@ -469,58 +441,35 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             if ((mask >> t) & 1u) taps_packed |= (unsigned long long)t << (4 * ntaps++);
     }
     const int nk = p.a_mode == ADA_A_PLAIN ? p.K / BK : ntaps * cps;
-    // ---- constants of the generated 4-wave loop (LOOP 2 / 3); fragments in v[0:127], accumulators in a[0:255] while it runs ----
-    [[maybe_unused]] unsigned p4_abase = 0, p4_bbase = 0, p4_m0s0 = 0, p4_period = 0x7fffffffu, p4_cnt = 0, p4_jump = 0;
-    [[maybe_unused]] long a0o = 0, b0o = 0, a1o = 0, b1o = 0, a2o = 0, b2o = 0;
-    constexpr unsigned OOB = 0x7fffffffu;     // a scalar offset beyond num_records: the copy zero-fills without fetching
-    // the asm needs the two buffer resources in SGPRs: rebuild them from readfirstlane'd pointer halves so that their uniformity is
-    // provable (the tile bases come out of float-reciprocal divisions, i.e. VALU registers -- cdna_hip_programming.md T20)
-    auto uniform_rsrc = [](const void* ptr) {
-        const unsigned long long v = (unsigned long long)ptr;
-        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x20000);
-    };
     if constexpr (PIPE4) {
+        // everything between here and the epilogue's first dump() is the generated asm: fragments in v[0:127], accumulators in a[0:255]
         const int l15 = lane & 15, q4 = lane >> 4;
         const unsigned lds0 = (unsigned)(size_t)smem;
         const unsigned coff0 = (unsigned)((q4 ^ ((l15 >> 1) & 7)) * 16);
-        p4_abase = lds0 + (unsigned)((wm * 128 + l15) * RB) + coff0;
-        p4_bbase = lds0 + (unsigned)(A_BYTES + (wn * 128 + l15) * RB) + coff0;
-        p4_m0s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)wave * 1024u));
+        const unsigned abase = lds0 + (unsigned)((wm * 128 + l15) * RB) + coff0;
+        const unsigned bbase = lds0 + (unsigned)(A_BYTES + (wn * 128 + l15) * RB) + coff0;
+        const unsigned m0s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)wave * 1024u));
+        constexpr unsigned OOB = 0x7fffffffu;     // a scalar offset beyond num_records: the copy zero-fills without fetching
+        long a0o, b0o, a1o = 0, b1o = 0, a2o = 0, b2o = 0;
         slab_offsets(0, a0o, b0o);
         if (nk > 1) slab_offsets(1, a1o, b1o);
         if (nk > 2) slab_offsets(2, a2o, b2o);
+        unsigned period = 0x7fffffffu, cnt = 0, jump = 0;
         if (p.a_mode != ADA_A_PLAIN) {   // 3x3 conv: consecutive k-tiles of an input row (three taps) are contiguous; every 3 * cps k-tiles the
-            p4_period = (unsigned)(3 * cps);   // A window moves down one padded input row
-            p4_cnt = 2u % p4_period;
-            p4_jump = (unsigned)(((long)(p.Wp - 3) * p.lda) * 2);
+            period = (unsigned)(3 * cps);   // A window moves down one padded input row
+            cnt = 2u % period;
+            jump = (unsigned)(((long)(p.Wp - 3) * p.lda) * 2);
         }
-    }
-    // ---- persistent kernel (LOOP 3): resources of the CURRENT tile's operands + the copies of its k-tiles 0 / 1 -> stages 0 / 1 ----
-    [[maybe_unused]] __amdgpu_buffer_rsrc_t p4_ra = uniform_rsrc(a_tile), p4_rb = uniform_rsrc(b_tile);
-    [[maybe_unused]] auto first_copies = [&](__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb) {
-        char* s0 = smem + wave * 1024;
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const int soa = st == 0 ? (int)(a0o * 2) : (nk > 1 ? (int)(a1o * 2) : (int)OOB);
-            const int sob = st == 0 ? 0 : (nk > 1 ? 128 : (int)OOB);
-#pragma unroll
-            for (int it = 0; it < A_IT; ++it)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(s0 + st * STAGE_BYTES + it * (NT * 16)), 16, (int)a_off[it], soa, 0, 0);
-#pragma unroll
-            for (int it = 0; it < B_IT; ++it)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(s0 + st * STAGE_BYTES + A_BYTES + it * (NT * 16)), 16, (int)b_off[it], sob, 0, 0);
-        }
-    };
-    if constexpr (PERSIST) first_copies(p4_ra, p4_rb);
-    [[maybe_unused]] bool more_tiles = false;
-    [[maybe_unused]] int vbn = 0;
-    for (;;) {   // tile loop: one trip unless PERSIST
-    if constexpr (PERSIST) {
-        pipe4_main_loop_np(p4_ra, p4_rb, a_off, b_off, p4_abase, p4_bbase, p4_m0s0, (unsigned)(a2o * 2), (unsigned)nk, p4_period, p4_cnt, p4_jump);
-    } else if constexpr (PIPE4) {
-        pipe4_main_loop(p4_ra, p4_rb, a_off, b_off, p4_abase, p4_bbase, p4_m0s0, (unsigned)(a0o * 2), nk > 1 ? (unsigned)(a1o * 2) : OOB, nk > 1 ? 128u : OOB,
-                        (unsigned)(a2o * 2), (unsigned)nk, p4_period, p4_cnt, p4_jump);
+        // the asm needs the two buffer resources in SGPRs: rebuild them from readfirstlane'd pointer halves so that their uniformity is
+        // provable (the tile bases come out of float-reciprocal divisions, i.e. VALU registers -- cdna_hip_programming.md T20)
+        auto uniform_rsrc = [](const void* ptr) {
+            const unsigned long long v = (unsigned long long)ptr;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+            return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x20000);
+        };
+        const __amdgpu_buffer_rsrc_t a_rs = uniform_rsrc(a_tile), b_rs = uniform_rsrc(b_tile);
+        pipe4_main_loop(a_rs, b_rs, a_off, b_off, abase, bbase, m0s0, (unsigned)(a0o * 2), nk > 1 ? (unsigned)(a1o * 2) : OOB, nk > 1 ? 128u : OOB,
+                        (unsigned)(a2o * 2), (unsigned)nk, period, cnt, jump);
     } else {
     // Offsets of the next slab to stage.  Plain operands walk k-step j directly; a 3x3 conv walks (active tap, k-step inside the tap) with two
     // scalar counters (no division per k-step), the taps taken from taps_packed.  The walk state is passed and returned BY VALUE: captured by
@@ -616,73 +565,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
 
     // ---- epilogue: transpose through a wave-private LDS slab, then float4 per lane ----------------
     // The wave tile is walked in 32-row x GW-column groups (GW = 64, or 32 for the narrow tiles).
-    __syncthreads();  // every wave is done reading the last stage before the slabs overwrite it (PERSIST: before the next tile's first slabs land in it)
+    __syncthreads();  // every wave is done reading the last stage before the slabs overwrite it
     if (p.dbg) t_loop = __builtin_amdgcn_s_memtime();
-    // Persistent kernel: set-up + first copies of the NEXT tile of this workgroup, in flight under this tile's epilogue (whose slabs sit above the stages).
-    // The per-lane copy offsets are computed HERE for the copies and AGAIN behind the epilogue for the main loop (~150 VALU operations per tile):
-    // carried through the epilogue they -- and what the compiler derives from them ahead of time -- cost ~60 VGPRs that the epilogue does not have
-    // (the generated loop owns v0-v135 and every AGPR).
-    auto restage = [&](int vb_next) {
-        int tm_, tn_;
-        tile_of(vb_next, tm_, tn_);
-        int srow_ = srow, gchunk_ = gchunk;
-        asm volatile("" : "+v"(srow_), "+v"(gchunk_));      // laundered: their products with lda / K are loop-invariant 64-bit VGPR pairs otherwise
-        const int m2 = tm_ * BM, n2 = tn_ * BN;
-        const uint32_t mf2 = (uint32_t)m2 < (uint32_t)p.M ? (uint32_t)m2 : (uint32_t)p.M - 1;
-        const long el2 = a_row_base(mf2);
-        a_tile = p.A + el2;
-        b_tile = p.W + (long)(n2 < p.N ? n2 : p.N - 1) * p.K;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            uint32_t m = (uint32_t)(m2 + it * ROWS_PER_PASS + srow_);
-            if (m >= (uint32_t)p.M) m = (uint32_t)p.M - 1;
-            a_off[it] = (uint32_t)((a_row_base(m) - el2 + gchunk_ * 8) * 2);
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            int n = n2 + it * ROWS_PER_PASS + srow_;
-            if (n >= p.N) n = p.N - 1;
-            b_off[it] = (uint32_t)(((long)(n - (n2 < p.N ? n2 : p.N - 1)) * p.K + gchunk_ * 8) * 2);
-        }
-        p4_ra = uniform_rsrc(a_tile);
-        p4_rb = uniform_rsrc(b_tile);
-    };
-    if constexpr (PERSIST) {
-        vbn = vb + (int)gridDim.x;
-        more_tiles = vbn < nblk;
-        if (more_tiles) {
-            restage(vbn);
-            first_copies(p4_ra, p4_rb);
-#pragma unroll
-            for (int it = 0; it < A_IT; ++it) asm volatile("" ::"v"(a_off[it]));     // consumed: nothing of this set-up lives on through the epilogue
-        }
-    }
-    // Persistent kernel: the epilogue sits inside the tile loop, and everything it derives from the lane index (slab addresses, row / column
-    // group of the lane, pad-walk starts) is loop-invariant -- hoisted, it would have to stay in VGPRs across the generated main loop, which owns
-    // v0-v135 (measured: 50 spilled VGPRs).  The lane index is laundered once per tile so that those values are recomputed (a few dozen VALU ops).
-    int lane_l_ = lane;
-    if constexpr (PERSIST) asm volatile("" : "+v"(lane_l_));
-    const int lane = lane_l_;      // shadows the kernel-scope lane for the rest of the tile
-    float zf_ = 0.0f;              // ... and so is the zero the residual registers start from (32 hoisted zero VGPRs otherwise)
-    if constexpr (PERSIST) asm volatile("" : "+v"(zf_));
-    const float zf = zf_;
     constexpr int GW = TJ >= 2 ? 64 : 32;      // columns per epilogue group
     constexpr int GJ = GW / 32;                // MFMA tiles per group
     constexpr int NG = TJ / GJ;                // groups per wave-tile row block
-    // slab row stride in floats.  Padded by 4 so that the four 16-lane quarters of a 16x16 dump (rows 4 apart) hit disjoint banks and consecutive
-    // rows sit one 16-byte bank slot apart for the readers' ds_read_b128 lane groups.  The persistent kernel's slabs live in the 32 KB ABOVE the two
-    // stages (which hold the next tile's first k-tiles meanwhile) where there is no room for padding: rows are 64 floats, and instead
-    //   * logical row rho of a 32-row pass is stored at physical row  (rho & 16) | ((rho & 3) << 2) | ((rho >> 2) & 3)   (the two 2-bit fields swapped),
-    //   * its 16-float column blocks are XOR-ed with rho & 3.
-    // Dump: a lane's four rows 4q + rr of a 16x16 sub-tile land on physical rows 4 rr + q in column block jb ^ rr -- compile-time offsets off one base
-    // per block (ds_write2st64_b32 pairs the two row halves a = 0 / 1).  Readers (float4 per lane, 16 lanes per row, rows 4k + rsub): the lane always
-    // fetches physical position (16 (k >> 2) + 4 rsub + (k & 3), 4 (lane & 15)) -- one 16-byte slot per lane index: conflict-free in every
-    // ds_read_b128 lane group (MI355X_MICROARCH.md, LDS) -- and what it holds there are the LOGICAL columns 4 cg, cg = (lane & 15) ^ (4 rsub).
-    constexpr int SW = PERSIST ? GW : GW + 4;
-    static_assert(!PERSIST || GW == 64, "persistent kernel: 64-column epilogue groups");
-    static_assert(PERSIST || NWAVES * 32 * SW * 4 <= 2 * STAGE_BYTES, "epilogue slabs must fit in the stage buffers");
-    static_assert(!PERSIST || EPI == EPI_STD || EPI == EPI_GELU, "persistent kernel: standard / GELU epilogues (float4 paths) only");
-    float* slab = (float*)(smem + (PERSIST ? 2 * STAGE_BYTES : 0) + wave * (32 * SW * 4));
+    constexpr int SW = GW + 4;                 // slab row stride in floats: the four 16-lane quarters of a 16x16 dump (rows 4 apart) hit disjoint banks
+    static_assert(NWAVES * 32 * SW * 4 <= 2 * STAGE_BYTES, "epilogue slabs must fit in the stage buffers");
+    float* slab = (float*)(smem + wave * (32 * SW * 4));
     const int flags = p.flags;
     const int mbase = m0 + wm * TI * 32;
     const int nwave = n0 + wn * TJ * 32;
@@ -691,26 +581,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
     // lane and sub-tile, written as two ds_write2_b32 (rows rr, rr+1) off one base address per row half a (hipcc pairs only a
     // third of the stores on its own)
     const unsigned slab_lds = (unsigned)(size_t)slab + (unsigned)((4 * (lane >> 4) * SW + (lane & 15)) * 4);
-    // persistent kernel: one base per physical column block j' (see the layout above): slab + (q * 64 + 16 j' + c) floats, q = lane >> 4, c = lane & 15
-    unsigned slab_sw[4];
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) slab_sw[jb] = (unsigned)(size_t)slab + (unsigned)(((lane >> 4) * SW + 16 * jb + (lane & 15)) * 4);
     auto dump = [&](int i, int g) {
-        if constexpr (PERSIST) {
-            // element rr of the sub-tiles (a = 0, b) and (a = 1, b): physical rows 4 rr + q and 16 + 4 rr + q, column block (2 jj + b) ^ rr
-#pragma unroll
-            for (int jj = 0; jj < GJ; ++jj)
-#pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2)
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int ar = 16 * (4 * i + (g * GJ + jj)) + 4 * b2 + rr;      // a = 0; a = 1 is 8 registers on
-                        float v0, v1;
-                        asm volatile("v_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]" : "=v"(v0), "=v"(v1) : "i"(ar), "i"(ar + 8));
-                        asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(slab_sw[(2 * jj + b2) ^ rr]), "v"(v0), "v"(v1), "i"(4 * rr), "i"(16 + 4 * rr) : "memory");
-                    }
-            return;
-        }
 #pragma unroll
         for (int jj = 0; jj < GJ; ++jj)
 #pragma unroll
@@ -809,7 +680,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
         //      bookkeeping: 10.7 k cycles per 256x256 tile for fp16 output, 35 k for the fp32 residual update, against 4-8 k
         //      for this path (profiles/r01_g_gemm_tile_anatomy.txt) -- the epilogue is VALU-issue-bound, not memory-bound.
         const bool has_bias = (flags & ADA_EP_BIAS) != 0, has_gamma = (flags & ADA_EP_GAMMA) != 0;
-        if (!PERSIST && !p.out_f32 && !(flags & ADA_EP_RESIDUAL)) {     // (persistent kernel: every output goes through the float4 path below -- its slab layout serves 16 lanes per row)
+        if (!p.out_f32 && !(flags & ADA_EP_RESIDUAL)) {
             constexpr int CG = GW / 8, RPI = 64 / CG;
             // Lane -> (slab row rsub, column group cg).  The slab reads are ds_read_b128, serviced in the lane groups {0-3, 12-15, 20-27},
             // {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS): with cg = lane % CG two lanes of every group met on one 16-byte bank slot
@@ -873,8 +744,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             }
         } else {
             constexpr int CG = GW / 4, RPI = 64 / CG, NKI = 32 / RPI, NPASS = NG * TI;
-            // column group rotated by the row: see above; persistent kernel: the lane's LOGICAL column group at its fixed physical slot (layout comment)
-            const int rsub = lane / CG, cg = PERSIST ? ((lane & 15) ^ (4 * rsub)) : CG == 16 ? ((lane - rsub) & 15) : lane % CG;
+            const int rsub = lane / CG, cg = CG == 16 ? ((lane - rsub) & 15) : lane % CG;   // column group rotated by the row: see above
             const bool has_res = (flags & ADA_EP_RESIDUAL) != 0;
             const bool relu_f = (flags & ADA_EP_RELU_F32) != 0, relu_o = (flags & ADA_EP_RELU_OP) != 0;
             const long ldr = p.ldr, ldf = p.ldo_f32, ldo = p.ldo_op;
@@ -887,7 +757,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             constexpr bool AHEAD = (NWAVES == 8 && TJ <= 2) || PIPE4;
             float4 rcur[NKI], rnext[AHEAD ? NKI : 1];
 #pragma unroll
-            for (int k = 0; k < NKI; ++k) rcur[k] = make_float4(zf, zf, zf, zf);
+            for (int k = 0; k < NKI; ++k) rcur[k] = make_float4(0, 0, 0, 0);
             if (AHEAD && has_res) {
                 const float* r0 = rptr(0);
 #pragma unroll
@@ -920,8 +790,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 if (pad) walk = pad_start(p, (uint32_t)mrow);
 #pragma unroll
                 for (int k = 0; k < NKI; ++k) {
-                    float4 v = PERSIST ? *(const float4*)(slab + (16 * (k >> 2) + 4 * rsub + (k & 3)) * SW + 4 * (lane & 15))
-                                       : *(const float4*)(slab + (k * RPI + rsub) * SW + 4 * cg);
+                    float4 v = *(const float4*)(slab + (k * RPI + rsub) * SW + 4 * cg);
                     v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                     if constexpr (EPI == EPI_GELU) {
                         v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
@@ -959,7 +828,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 }
             }
         }
-    } else if (!PERSIST && !p.out_f32 && !(flags & ADA_EP_RESIDUAL) && (p.ldo_op & 7) == 0 && (EPI != EPI_SHUFFLE || (p.shuffle_c & 7) == 0)) {
+    } else if (!p.out_f32 && !(flags & ADA_EP_RESIDUAL) && (p.ldo_op & 7) == 0 && (EPI != EPI_SHUFFLE || (p.shuffle_c & 7) == 0)) {
         // ---- operand-only output: 8 columns per lane -> one 16-byte store per row segment ----------------
         constexpr int CG = GW / 8;       // 8-column groups per row (4 or 8)
         constexpr int RPI = 64 / CG;     // rows per wave-wide access (16 or 8)
@@ -1051,7 +920,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
         constexpr int RPI = 64 / CG;     // rows covered by one wave-wide float4 read (8 or 4)
         constexpr int NKI = 32 / RPI;
         constexpr int NPASS = NG * TI;   // pass index q = g * TI + i
-        const int rsub = lane / CG, cg = PERSIST ? ((lane & 15) ^ (4 * rsub)) : lane % CG;     // persistent kernel: see the slab layout comment
+        const int cg = lane % CG, rsub = lane / CG;
         const bool has_res = (flags & ADA_EP_RESIDUAL) != 0;
         auto col_of = [&](int g) { return nwave + g * GW + 4 * cg; };
         auto res_ptr = [&](int q, int k) -> const float* {
@@ -1075,7 +944,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
         constexpr bool AHEAD = (NWAVES == 8 && TJ <= 2) || PIPE4;
         float4 rcur[NKI], rnext[AHEAD ? NKI : 1];
 #pragma unroll
-        for (int k = 0; k < NKI; ++k) rcur[k] = make_float4(zf, zf, zf, zf);
+        for (int k = 0; k < NKI; ++k) rcur[k] = make_float4(0, 0, 0, 0);
         if (AHEAD && has_res) {
 #pragma unroll
             for (int k = 0; k < NKI; ++k) rcur[k] = *(const float4*)res_ptr(0, k);
@@ -1111,7 +980,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             for (int k = 0; k < NKI; ++k) {
                 const int row = k * RPI + rsub;
                 const int m = mbase + i * 32 + row;
-                float4 v = PERSIST ? *(const float4*)(slab + (16 * (k >> 2) + 4 * rsub + (k & 3)) * SW + 4 * (lane & 15)) : *(const float4*)(slab + row * SW + 4 * cg);
+                float4 v = *(const float4*)(slab + row * SW + 4 * cg);
                 v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                 if constexpr (EPI == EPI_GELU) {
                     v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
@@ -1159,16 +1028,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             }
         }
     }
-    if constexpr (PERSIST) {
-        if (!more_tiles) break;
-        vb = vbn;
-        restage(vb);                 // again: the copy offsets / resources the main loop of the next tile walks (see above)
-        tile_of(vb, tm, tn);
-        m0 = tm * BM; n0 = tn * BN;
-    } else {
-        break;
-    }
-    }   // tile loop
     // ---- LayerNorm tail (ada_igemm_args.ln_out): the LayerNorm that follows proj / fc2 (reference block.py:84,87) reads exactly the rows this
     //      launch has just written to the fp32 residual stream.  Every tile publishes its part of the row panel (write-through stores above, the
     //      wave's stores drained, one ticket per tile on the panel's counter); the tile that draws the last ticket normalises the panel's rows
@@ -1275,13 +1134,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
 }
 
 static std::atomic<int> g_group_override{0};  // debug: force the column-group width (0 = model)
-static std::atomic<int> g_persist_grid{0};    // debug: workgroups of the persistent kernel (0 = one per CU)
 static thread_local int g_last_tile = -1;   // tile configuration of the calling thread's most recent launch (ada_debug_last_tile)
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, int LOOP = 0>
 int launch_cfg(IgemmDev& d, hipStream_t stream) {
     constexpr int NT = WAVES_M * WAVES_N * 64;
-    constexpr int SMEM = 2 * (BM + BN) * BK * 2 + (LOOP == 3 ? 32 * 1024 : 0);   // persistent kernel: + the epilogue slabs above the stages (160 KB in all)
+    constexpr int SMEM = 2 * (BM + BN) * BK * 2;
     d.tiles_m = (d.M + BM - 1) / BM;
     d.tiles_n = (d.N + BN - 1) / BN;
     {
@@ -1309,11 +1167,7 @@ int launch_cfg(IgemmDev& d, hipStream_t stream) {
         }
     });
     g_last_tile = (BM == 256 && BN == 32 ? 0 : BM == 128 && BN == 64 ? 1 : BM == 256 && BN == 128 ? 2 : BM == 256 && BN == 256 ? 3 : 4) + 100 * LOOP;
-    long nblk = (long)d.tiles_m * d.tiles_n;
-    if (LOOP == 3) {   // persistent: one workgroup per CU (a multiple of 8, so a workgroup's tile walk stays on its XCD); the debug hook shrinks the grid
-        const int cap = g_persist_grid.load(std::memory_order_relaxed);      // so that small test problems walk several tiles per workgroup
-        if (nblk > (cap > 0 ? cap : 256)) nblk = cap > 0 ? cap : 256;
-    }
+    const long nblk = (long)d.tiles_m * d.tiles_n;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), SMEM, stream, d);
     return ada_check_launch("ada_igemm");
 }
@@ -1333,20 +1187,6 @@ static inline double tile_time(long M, long N, int bm, int bn, int occ, double e
 // 4-wave loop where its main loop outweighs its slower prologue / epilogue (measured: k-loops of >= 128 k-tiles)
 // (its scalar A-offset counters assume a monotonic walk: a split operand, whose third k segment re-reads the first, stays on the 8-wave loop)
 static inline bool use_pipe4(const IgemmDev& d) { return d.a_dup_seg == 0 && d.a_wrap == 0 && d.tap_cols == 0 && d.ln_out == nullptr && (d.variant >= 16 || (d.variant == 0 && d.K >= 8192)); }
-// ... and its persistent form (variant 32 forces it wherever the 4-wave loop applies; ADA_PERSIST_MIN_TILES / _MAX_K tune the default choice)
-static std::atomic<int> g_persist_min_tiles{-1}, g_persist_min_k{0};
-static inline bool use_persist(const IgemmDev& d, long tiles) {
-    if (d.variant >= 32) return true;
-    if (d.variant != 0) return false;
-    const int mt = g_persist_min_tiles.load(std::memory_order_relaxed);
-    return mt >= 0 && tiles >= mt && d.K >= g_persist_min_k.load(std::memory_order_relaxed);
-}
-static inline bool want_pipe4(const IgemmDev& d) {   // the 4-wave loop in either form
-    if (use_pipe4(d)) return true;
-    if (d.a_dup_seg != 0 || d.a_wrap != 0 || d.tap_cols != 0 || d.ln_out != nullptr || d.variant != 0) return false;
-    const long tiles = (long)((d.M + 255) / 256) * ((d.N + 255) / 256);
-    return use_persist(d, tiles);
-}
 
 template <int EPI>
 int launch_epi(IgemmDev& d, hipStream_t s, int force) {
@@ -1374,7 +1214,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force) {
     if ((d.flags & ADA_EP_ROWSTATS) && cfg == 0) cfg = 1;
     if constexpr (EPI == EPI_SWIGLU) {
         if (cfg == 4 || cfg == 2) return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
-        if (use_pipe4(d)) return launch_cfg<256, 256, 64, 2, 2, EPI, 2>(d, s);       // (no persistent form for the SwiGLU / pixel-shuffle epilogues)
+        if (use_pipe4(d)) return launch_cfg<256, 256, 64, 2, 2, EPI, 2>(d, s);
         return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
     } else if constexpr (EPI == EPI_TAIL) {
         return cfg == 0 ? launch_cfg<256, 32, 64, 4, 1, EPI>(d, s) : launch_cfg<128, 64, 64, 4, 1, EPI>(d, s);
@@ -1385,9 +1225,6 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force) {
             case 2: return launch_cfg<256, 128, 64, 4, 2, EPI>(d, s);
             case 4: return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
             default:
-                if constexpr (EPI == EPI_STD || EPI == EPI_GELU) {
-                    if (want_pipe4(d) && use_persist(d, (long)((d.M + 255) / 256) * ((d.N + 255) / 256))) return launch_cfg<256, 256, 64, 2, 2, EPI, 3>(d, s);
-                }
                 if (use_pipe4(d)) return launch_cfg<256, 256, 64, 2, 2, EPI, 2>(d, s);
                 return launch_cfg<256, 256, 64, 2, 4, EPI>(d, s);
         }
@@ -1399,7 +1236,7 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force) {
 // ---- tuning / diagnostic hooks (declared in include/ada_hip.h; process-global atomics, not needed for correct operation) ----
 static std::atomic<unsigned long long*> g_dbg{nullptr};
 static std::atomic<int> g_force_tile{-1};
-static std::atomic<int> g_variant{0};   // main loop of the 256x256 tile -- 0: by shape (default); 4: single-barrier 8-wave loop; 16: hand-scheduled 4-wave loop; 32: its persistent form
+static std::atomic<int> g_variant{0};   // main loop of the 256x256 tile -- 0: by shape (default); 4: single-barrier 8-wave loop; 16: hand-scheduled 4-wave loop
 static std::once_flag g_env_once;
 // A/B switches for kernel experiments: the environment (ADA_IGEMM_TILE / _GROUP / _VARIANT) presets the hooks below ONCE per process, and it
 // does so before the first explicit ada_debug_set_* call as well as before the first launch -- an explicit call always has the last word
@@ -1410,17 +1247,14 @@ static void apply_env_presets() {
         if (const char* gr = getenv("ADA_IGEMM_GROUP")) g_group_override.store(atoi(gr), std::memory_order_relaxed);
         if (const char* va = getenv("ADA_IGEMM_VARIANT")) {
             const int v = atoi(va);
-            g_variant.store(v >= 32 ? 32 : v >= 16 ? 16 : v >= 4 ? 4 : 0, std::memory_order_relaxed);
+            g_variant.store(v >= 16 ? 16 : v >= 4 ? 4 : 0, std::memory_order_relaxed);
         }
-        if (const char* pm = getenv("ADA_PERSIST_MIN_TILES")) g_persist_min_tiles.store(atoi(pm), std::memory_order_relaxed);
-        if (const char* pk = getenv("ADA_PERSIST_MIN_K")) g_persist_min_k.store(atoi(pk), std::memory_order_relaxed);
     });
 }
 // debug hook (not part of the stable ABI): override the tile configuration (-1 = heuristic)
 extern "C" void ada_debug_set_tile(int cfg) { apply_env_presets(); g_force_tile.store(cfg, std::memory_order_relaxed); }
-extern "C" void ada_debug_set_variant(int v) { apply_env_presets(); g_variant.store(v >= 32 ? 32 : v >= 16 ? 16 : v >= 4 ? 4 : 0, std::memory_order_relaxed); }
+extern "C" void ada_debug_set_variant(int v) { apply_env_presets(); g_variant.store(v >= 16 ? 16 : v >= 4 ? 4 : 0, std::memory_order_relaxed); }
 extern "C" void ada_debug_set_group(int g) { apply_env_presets(); g_group_override.store(g, std::memory_order_relaxed); }
-extern "C" void ada_debug_set_persist_grid(int n) { apply_env_presets(); g_persist_grid.store(n > 0 ? n : 0, std::memory_order_relaxed); }
 extern "C" int ada_debug_last_tile(void) { return g_last_tile; }
 // debug hook (not part of the stable ABI): device buffer of 8 x u64 per workgroup, or NULL to disable
 extern "C" void ada_debug_set_timestamps(void* dev_buf) { g_dbg.store((unsigned long long*)dev_buf, std::memory_order_relaxed); }

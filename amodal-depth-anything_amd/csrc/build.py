@@ -89,30 +89,6 @@ def isa_guard(src, asm_path, kinds):
         raise RuntimeError(f"{src}: ISA guard failed ({len(problems)} finding(s), listing {asm_path}):\n  " + "\n  ".join(problems[:20]))
 
 
-SCRATCH_MAX_PERSIST = 96     # bytes per lane
-
-
-def check_persist_scratch(asm_path, names):
-    """Persistent GEMM kernels that use scratch: nothing of it inside the generated main loop (where a spill per k-tile would hide, which is what the
-    no-scratch rule exists for); the tile loop around it may park / reload a few values per TILE (~70 k cycles of work)."""
-    import isa_guard as G
-    for name, body in G.kernels(open(asm_path).read()).items():
-        if name not in names:
-            continue
-        inside, seen = False, False
-        for no, ins in body:
-            if G.LABEL.match(ins):
-                if "LPIPE4_BEGIN" in ins:
-                    inside = seen = True
-                elif "LPIPE4_END" in ins:
-                    inside = False
-                continue
-            if inside and ins.startswith("scratch_"):
-                raise RuntimeError(f"{name}: scratch access inside the generated main loop: line {no}: {ins}")
-        if not seen:
-            raise RuntimeError(f"{name}: uses scratch but has no generated loop")
-
-
 def build(bf16=False, force=False, verbose=True, tag=None, extra_defines=()):
     """tag + extra_defines: experiment builds (libada_hip_<tag>.so with extra -D flags; select with ADA_HIP_LIB)."""
     defines = (["-DADA_OPERAND_BF16"] if bf16 else []) + list(extra_defines)
@@ -142,27 +118,10 @@ def build(bf16=False, force=False, verbose=True, tag=None, extra_defines=()):
             if res.returncode != 0:
                 sys.stderr.write(res.stderr)
                 raise subprocess.CalledProcessError(res.returncode, cmd)
-            # one block of remarks per kernel: "Function Name: <mangled>" ... "ScratchSize [bytes/lane]: N" ... "VGPRs Spill: N"
-            usage, bad, name = [], [], "?"
-            for ln in res.stderr.splitlines():
-                if "Function Name:" in ln:
-                    name = ln.split("Function Name:")[1].split()[0]
-                if "ScratchSize" in ln or "VGPRs Spill" in ln:
-                    usage.append(ln)
-                    if not ln.rstrip().endswith(": 0 [-Rpass-analysis=kernel-resource-usage]"):
-                        bad.append((name, ln))
-            # The persistent 4-wave GEMM kernels (LOOP = 3: ...ELi3EEE) may park a few loop-invariant values in scratch: the generated main loop owns
-            # v0-v135 and a[0:255], so what lives across it has 120 registers.  Tolerated up to SCRATCH_MAX_PERSIST bytes per lane and never inside
-            # the generated loop (checked on the listing below): a handful of scratch accesses per 256 x 256 tile.
-            tolerated = {n for n, ln in bad if src == "ada_igemm.hip" and n.endswith("ELi3EEEvNS_8IgemmDevE")}
-            hard = [ln for n, ln in bad if n not in tolerated]
-            for n, ln in bad:
-                if n in tolerated and "ScratchSize" in ln and int(ln.split("]:")[1].split()[0]) > SCRATCH_MAX_PERSIST:
-                    hard.append(ln)
-            if not usage or hard:
-                raise RuntimeError(f"{src}: the kernel must not use scratch / spill registers:\n" + "\n".join(hard or ["no resource-usage remarks found"]))
-            if tolerated:
-                check_persist_scratch(os.path.join(objdir, src.replace(".hip", f"-hip-amdgcn-amd-amdhsa-{ARCH}.s")), tolerated)
+            usage = [ln for ln in res.stderr.splitlines() if "ScratchSize" in ln or "VGPRs Spill" in ln]
+            bad = [ln for ln in usage if not ln.rstrip().endswith(": 0 [-Rpass-analysis=kernel-resource-usage]")]
+            if not usage or bad:
+                raise RuntimeError(f"{src}: the kernel must not use scratch / spill registers:\n" + "\n".join(bad or ["no resource-usage remarks found"]))
         else:
             subprocess.check_call(cmd)
         if guarded:

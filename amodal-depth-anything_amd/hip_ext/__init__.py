@@ -30,7 +30,7 @@ EXPORTS = (
     "ada_abi_version", "ada_operand_dtype", "ada_last_error", "ada_igemm", "ada_attention_fwd",
     "ada_rowstats_finalize", "ada_pos_embed_resize", "ada_layernorm_fwd", "ada_layernorm_ex", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
     "ada_minmax_fwd", "ada_depth_stats_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd", "ada_dpt_tail_fwd", "ada_tapsum_resize_fwd",
-    "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_set_persist_grid", "ada_debug_last_tile",
+    "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
     "ada_debug_set_timestamps", "ada_debug_set_attention_variant", "ada_debug_count_saturated",
 )
 
@@ -142,7 +142,7 @@ def load(path: Optional[str] = None):
     lib.ada_tapsum_resize_fwd.restype = c_int
     lib.ada_depth_eval_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_float, c_float, c_void_p, c_void_p]
     lib.ada_depth_eval_fwd.restype = c_int
-    for name in ("ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_set_persist_grid", "ada_debug_set_attention_variant"):
+    for name in ("ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_set_attention_variant"):
         getattr(lib, name).argtypes = [c_int]
         getattr(lib, name).restype = None
     for name in ("ada_debug_set_timestamps",):
@@ -445,11 +445,6 @@ def debug_set_variant(v: int = 0):
 def debug_set_group(g: int = 0):
     _bump_epoch()
     load().ada_debug_set_group(int(g))
-
-
-def debug_set_persist_grid(n: int = 0):
-    _bump_epoch()
-    load().ada_debug_set_persist_grid(int(n))
 
 
 def debug_last_tile() -> int:

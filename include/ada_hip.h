@@ -389,14 +389,10 @@ int ada_selftest(void* scratch, int64_t scratch_bytes, void* stream);
  *                                4 128x128; -1 = heuristic (default)
  *   ada_debug_set_variant(v)     main loop of the 256x256 tile: 0 = chosen by shape (default: the hand-scheduled 4-wave loop for
  *                                k-loops of >= 128 k-tiles, the single-barrier 8-wave loop otherwise); 4 = always the 8-wave loop;
- *                                16 = always the hand-scheduled 4-wave loop (generated assembly, csrc/ada_igemm_pipe4.inc);
- *                                32 = its persistent form (one workgroup per CU walks the tiles; the next tile's first k-tiles are
- *                                copied under the current tile's epilogue)
- *   ada_debug_set_persist_grid(n) workgroups of the persistent kernel (0 = one per CU; tests use small grids so that a small
- *                                problem walks several tiles per workgroup)
+ *                                16 = always the hand-scheduled 4-wave loop (generated assembly, csrc/ada_igemm_pipe4.inc)
  *   ada_debug_set_group(g)       force the column-group width of the tile order (0 = traffic model)
  *   ada_debug_last_tile()        tile code of the calling thread's most recent ada_igemm launch
- *                                (+200 when the hand-scheduled 4-wave main loop ran, +300 for its persistent form), -1 before the first launch
+ *                                (+200 when the hand-scheduled 4-wave main loop ran), -1 before the first launch
  *   ada_debug_set_timestamps(p)  device buffer of 8 x u64 per workgroup receiving s_memtime stamps
  *                                of the single-barrier loop, or NULL (default)
  *   ada_debug_set_attention_variant(v)  5 = 4-wave kernel with the softmax interleaved between its MFMAs (default),
@@ -405,7 +401,6 @@ int ada_selftest(void* scratch, int64_t scratch_bytes, void* stream);
 void ada_debug_set_tile(int cfg);
 void ada_debug_set_variant(int v);
 void ada_debug_set_group(int g);
-void ada_debug_set_persist_grid(int n);
 int ada_debug_last_tile(void);
 void ada_debug_set_timestamps(void* dev_buf);
 void ada_debug_set_attention_variant(int v);

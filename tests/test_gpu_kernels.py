@@ -629,27 +629,25 @@ def test_patchify_split_precision(hip):
 # (ada_debug_set_variant: 16 = hand-scheduled 4-wave loop, 4 = single-barrier 8-wave loop) on problems that span >= 3 tile rows, end in
 # a ragged tile, and (for the wide ones) engage the column-group tile order.
 # =====================================================================================================================
-TILE_CASES = [(0, 4), (1, 4), (2, 4), (3, 4), (3, 16), (3, 32), (4, 4)]   # (tile cfg, main-loop variant: 4 single barrier, 16 4-wave asm, 32 persistent 4-wave asm)
+TILE_CASES = [(0, 4), (1, 4), (2, 4), (3, 4), (3, 16), (4, 4)]   # (tile cfg, main-loop variant: 4 single barrier, 8 phased)
 
 
 @pytest.fixture
 def forced_tile(hip):
-    def force(cfg, variant, grid=5):
+    def force(cfg, variant):
         hip.debug_set_tile(cfg)
         hip.debug_set_variant(variant)
-        hip.debug_set_persist_grid(grid if variant == 32 else 0)     # persistent kernel: 5 workgroups walk the test problem's 12-54 tiles
     yield force
     hip.debug_set_tile(-1)
     hip.debug_set_variant(0)
     hip.debug_set_group(0)
-    hip.debug_set_persist_grid(0)
 
 
 def _check_tile(hip, cfg, variant):
     code = hip.debug_last_tile()
     assert code % 100 == cfg, f"forced tile {cfg} but the launch used {code}"
     if cfg == 3:
-        assert code // 100 == {16: 2, 32: 3}.get(variant, 0), f"variant {variant} but tile code {code}"
+        assert code // 100 == {16: 2}.get(variant, 0), f"variant {variant} but tile code {code}"
 
 
 @pytest.mark.parametrize("cfg,variant", TILE_CASES)
@@ -693,36 +691,7 @@ def test_igemm_forced_tile_epilogues(hip, forced_tile, cfg, variant, epi):
         _close(out, lin - b.cpu(), what=f"tile {cfg}/{variant} plain", **loose)
 
 
-@pytest.mark.parametrize("grid", [0, 24, 7])
-@pytest.mark.parametrize("epi", ["bias_op", "ls_res"])
-def test_igemm_persistent_kernel_walks_tiles_like_one_workgroup_per_tile(hip, forced_tile, grid, epi):
-    """Variant 32 (one workgroup per CU walks tiles bid, bid + grid, ...; the next tile's first k-tiles are copied under the epilogue) on a problem of
-    43 x 9 = 387 tiles with a ragged last row panel, at the production grid (256) and at small grids (many tiles per workgroup; 7: not a multiple of
-    the 8 XCDs): bit-identical to the one-workgroup-per-tile 4-wave kernel (same main loop, same epilogue arithmetic, different schedule only)."""
-    op = _op(hip)
-    M, N, K = 42 * 256 + 130, 2304, 192
-    A = _rand(M, K, seed=261).to(op).to(DEV)
-    W = _rand(N, K, scale=K ** -0.5, seed=262).to(op).to(DEV)
-    b, g = _rand(N, seed=263).to(DEV), (_rand(N, seed=264) * 0.5 + 1).to(DEV)
-    outs = {}
-    for variant in (16, 32):
-        forced_tile(3, variant, grid)
-        if epi == "bias_op":
-            out = torch.full((M, N), float("nan"), dtype=op, device=DEV)
-            hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=W, bias=b, flags=hip.EP_BIAS, out_op=out, ldo_op=N)
-        else:
-            out = _rand(M, N, seed=265).to(DEV)
-            hip.igemm(M=M, N=N, K=K, A=A, lda=K, W=W, bias=b, gamma=g, res=out, ldr=N, flags=hip.EP_BIAS | hip.EP_GAMMA | hip.EP_RESIDUAL, out_f32=out, ldo_f32=N)
-        _check_tile(hip, 3, variant)
-        outs[variant] = out
-    assert torch.isfinite(outs[32].float()).all()
-    assert torch.equal(outs[16], outs[32]), f"persistent kernel differs: max abs {float((outs[16].float() - outs[32].float()).abs().max()):.3e}"
-    ref = A.float().cpu() @ W.float().cpu().T + b.cpu()
-    if epi == "bias_op":
-        _close(outs[32], ref, atol=2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="persistent bias->op")
-
-
-@pytest.mark.parametrize("cfg,variant", [(3, 8), (3, 4), (3, 32), (2, 8), (4, 8)])
+@pytest.mark.parametrize("cfg,variant", [(3, 8), (3, 4), (2, 8), (4, 8)])
 def test_igemm_forced_tile_column_groups_long_k(hip, forced_tile, cfg, variant):
     """N = 2304 (9 column tiles of 256) and K = 4096: the weight panel exceeds the L2 model's budget so the launcher walks
     the tiles in column groups (group_n < tiles_n); also run with the group width forced to 2 and to 1."""
@@ -741,7 +710,7 @@ def test_igemm_forced_tile_column_groups_long_k(hip, forced_tile, cfg, variant):
         _close(out, ref, 5e-4, what=f"tile {cfg}/{variant} group {group}")
 
 
-@pytest.mark.parametrize("cfg,variant", [(3, 8), (3, 4), (3, 16), (3, 32), (4, 8), (2, 8), (1, 8)])
+@pytest.mark.parametrize("cfg,variant", [(3, 8), (3, 4), (4, 8), (2, 8), (1, 8)])
 def test_igemm_forced_tile_conv3x3_pad_residual(hip, forced_tile, cfg, variant):
     """3x3 implicit GEMM (9 taps x 2 k-tiles), stride 1, fp32 + residual and ReLU'd zero-bordered NHWC outputs."""
     op = _op(hip)
@@ -765,7 +734,7 @@ def test_igemm_forced_tile_conv3x3_pad_residual(hip, forced_tile, cfg, variant):
     assert float(border.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("cfg,variant", [(3, 8), (3, 4), (3, 16), (4, 8)])
+@pytest.mark.parametrize("cfg,variant", [(3, 8), (3, 4), (4, 8)])
 def test_igemm_forced_tile_shuffle_and_swiglu(hip, forced_tile, cfg, variant):
     op = _op(hip)
     # ConvTranspose2d k = s = 2 as GEMM + pixel shuffle: N = 4 * 256 = 1024

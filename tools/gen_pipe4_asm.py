@@ -118,35 +118,28 @@ def k_tile(stage, first=False):
     return o
 
 
-def body(prologue=True):
-    """prologue=True: the loop issues the copies of k-tiles 0 / 1 itself (one workgroup per tile).  prologue=False: the persistent kernel's form --
-    the caller has issued them (under the epilogue of the previous tile) and the loop starts by waiting for them."""
+def main():
     L = []
-    L.append(q("LPIPE4_BEGIN_%=:"))
     L.append(q("; ==== ada_igemm 4-wave pipelined main loop (generated by tools/gen_pipe4_asm.py) ===="))
     L += [q("s_mov_b32 s91, 0x7fffffff"), q(f"s_add_u32 s90, %[m0s0], {STAGE}")]
     L += [q("v_mov_b32 v128, %[abase]"), q("v_xor_b32 v129, 64, %[abase]"), q(f"v_add_u32 v130, {STAGE}, %[abase]"), q("s_nop 0"),
           q(f"v_add_u32 v131, {STAGE}, v129"),
           q("v_mov_b32 v132, %[bbase]"), q("v_xor_b32 v133, 64, %[bbase]"), q(f"v_add_u32 v134, {STAGE}, %[bbase]"), q("s_nop 0"),
           q(f"v_add_u32 v135, {STAGE}, v133")]
-    if prologue:
-        # prologue: k-tile 0 -> stage 0, k-tile 1 -> stage 1
-        L.append(q("s_mov_b32 m0, %[m0s0]"))
+    # prologue: k-tile 0 -> stage 0, k-tile 1 -> stage 1
+    L.append(q("s_mov_b32 m0, %[m0s0]"))
+    L.append(q("s_nop 0"))
+    for idx in range(16):
+        L.append(q(copy_instr(idx, "%[sa0]", "0")))
+        L.append(q(f"s_add_u32 m0, m0, {PIECE}"))
         L.append(q("s_nop 0"))
-        for idx in range(16):
-            L.append(q(copy_instr(idx, "%[sa0]", "0")))
-            L.append(q(f"s_add_u32 m0, m0, {PIECE}"))
-            L.append(q("s_nop 0"))
-        L.append(q("s_mov_b32 m0, s90"))
+    L.append(q("s_mov_b32 m0, s90"))
+    L.append(q("s_nop 0"))
+    for idx in range(16):
+        L.append(q(copy_instr(idx, "%[sa1]", "%[sb1]")))
+        L.append(q(f"s_add_u32 m0, m0, {PIECE}"))
         L.append(q("s_nop 0"))
-        for idx in range(16):
-            L.append(q(copy_instr(idx, "%[sa1]", "%[sb1]")))
-            L.append(q(f"s_add_u32 m0, m0, {PIECE}"))
-            L.append(q("s_nop 0"))
-        L += [q("s_waitcnt vmcnt(16)"), q("s_barrier")]
-    else:
-        # the copies of k-tiles 0 / 1 were issued by every wave long ago (and this wave's epilogue stores sit in the same counter): drain, meet
-        L += [q("s_waitcnt vmcnt(0)"), q("s_barrier")]
+    L += [q("s_waitcnt vmcnt(16)"), q("s_barrier")]
     for idx in range(16):
         L.append(q(read_instr(0, 0, idx)))
     L += [q("s_mov_b32 s84, 0"), q("s_mov_b32 s85, %[sa2]"), q("s_mov_b32 s86, 256"), q("s_mov_b32 s87, %[cnt]"), q("s_waitcnt lgkmcnt(0)")]
@@ -162,26 +155,11 @@ def body(prologue=True):
     L.append(q("LPIPE4_END_%=:"))
     # the zero-filling copies past the last k-tile must not land in the epilogue's LDS slabs; MFMA results need wait states before v_accvgpr_read
     L += [q("s_waitcnt vmcnt(0)"), q("s_nop 15"), q("s_nop 15")]
-    return L
 
-
-def emit(f, name, L, prologue):
     clob = [f'"v{i}"' for i in range(136)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(84, 94)] + ['"m0"', '"scc"', '"memory"']
     ins = ['[ra] "s"(ra)', '[rb] "s"(rb)'] + [f'[ao{i}] "v"(ao[{i}])' for i in range(8)] + [f'[bo{i}] "v"(bo[{i}])' for i in range(8)] + \
-          ['[abase] "v"(abase)', '[bbase] "v"(bbase)', '[m0s0] "s"(m0s0)'] + (['[sa0] "s"(sa0)', '[sa1] "s"(sa1)', '[sb1] "s"(sb1)'] if prologue else []) + \
-          ['[sa2] "s"(sa2)', '[nk] "s"(nk)', '[period] "s"(period)', '[cnt] "s"(cnt)', '[jump] "s"(jump)']
-    f.write(f"ADA_DEV void {name}(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, const uint32_t (&ao)[8], const uint32_t (&bo)[8], uint32_t abase,\n")
-    f.write("                             uint32_t bbase, uint32_t m0s0, " + ("uint32_t sa0, uint32_t sa1, uint32_t sb1, " if prologue else "") +
-            "uint32_t sa2, uint32_t nk, uint32_t period,\n")
-    f.write("                             uint32_t cnt, uint32_t jump) {\n")
-    f.write("    asm volatile(\n")
-    for ln in L:
-        f.write("        " + ln + "\n")
-    f.write("        :\n        : " + ", ".join(ins) + "\n        : " + ", ".join(clob) + ");\n}\n")
-
-
-def main():
-    L, L2 = body(True), body(False)
+          ['[abase] "v"(abase)', '[bbase] "v"(bbase)', '[m0s0] "s"(m0s0)', '[sa0] "s"(sa0)', '[sa1] "s"(sa1)', '[sb1] "s"(sb1)', '[sa2] "s"(sa2)',
+           '[nk] "s"(nk)', '[period] "s"(period)', '[cnt] "s"(cnt)', '[jump] "s"(jump)']
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_pipe4_asm.py -- do not edit; the schedule (READ_SLOTS / COPY_SLOTS) lives in the generator.\n")
         f.write("// Main loop of the 4-wave 256x256x64 tile: see the generator's docstring for the register plan and the phase structure.\n")
@@ -189,13 +167,16 @@ def main():
         f.write("// this lane's fragment reads (stage 0, k half 0); m0s0: LDS byte address of this wave's copy destination in stage 0; sa0 / sa1 / sb1: scalar byte\n")
         f.write("// offsets of k-tiles 0 / 1 (0x7fffffff = no such tile); sa2: A offset of k-tile 2; period / cnt / jump: the conv row jump (bytes) every\n")
         f.write("// `period` k-tiles, cnt = 2 % period.\n")
-        f.write("// pipe4_main_loop_np: the persistent kernel's form -- the copies of k-tiles 0 / 1 are already in flight (issued by the caller under the\n")
-        f.write("// previous tile's epilogue); the loop starts with s_waitcnt vmcnt(0) + s_barrier.\n")
         f.write("#ifdef ADA_OPERAND_BF16\n#define ADA_MFMA_SUFFIX \"bf16\"\n#else\n#define ADA_MFMA_SUFFIX \"f16\"\n#endif\n")
-        emit(f, "pipe4_main_loop", L, True)
-        emit(f, "pipe4_main_loop_np", L2, False)
+        f.write("ADA_DEV void pipe4_main_loop(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, const uint32_t (&ao)[8], const uint32_t (&bo)[8], uint32_t abase,\n")
+        f.write("                             uint32_t bbase, uint32_t m0s0, uint32_t sa0, uint32_t sa1, uint32_t sb1, uint32_t sa2, uint32_t nk, uint32_t period,\n")
+        f.write("                             uint32_t cnt, uint32_t jump) {\n")
+        f.write("    asm volatile(\n")
+        for ln in L:
+            f.write("        " + ln + "\n")
+        f.write("        :\n        : " + ", ".join(ins) + "\n        : " + ", ".join(clob) + ");\n}\n")
         f.write("#undef ADA_MFMA_SUFFIX\n")
-    print(OUT, len(L), "+", len(L2), "asm lines")
+    print(OUT, len(L), "asm lines")
 
 
 if __name__ == "__main__":

@@ -327,7 +327,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_v3(const op_t* __rest
 #ifndef ADA_ATTN_MFMA_ROWSUM
 #define ADA_ATTN_MFMA_ROWSUM 1
 #endif
-__global__ __launch_bounds__(256, 2) void attention_kernel_mix(const op_t* __restrict__ qkv, op_t* __restrict__ out,
+#ifndef ADA_ATTN_OCC
+#define ADA_ATTN_OCC 2     // workgroups (= waves per SIMD) the register budget is set for; 3 is an experiment build (-DADA_ATTN_OCC=3: <= 168 VGPRs)
+#endif
+__global__ __launch_bounds__(256, ADA_ATTN_OCC) void attention_kernel_mix(const op_t* __restrict__ qkv, op_t* __restrict__ out,
                                                                int n_tok, int heads, int nqb, int n_bh) {
     __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE + 2 * V_TILE];   // [K0 | K1 | V0 | V1]
 

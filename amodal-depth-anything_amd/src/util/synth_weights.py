@@ -74,7 +74,7 @@ def fill_state_dict_(sd: Dict[str, torch.Tensor], seed: int = 0, tail: str = "no
         # same stream, same values) and scale in place: one pass over memory instead of three temporaries -- the ViT-G fill is 4.4 GB and its cost
         # is memory traffic and page faults, not the generator.  Every in-place sequence below performs the same fp32 operations in the same order
         # as the expression it replaces (x * a then + b), so the values are bit-identical (tests/test_synth_weights_cpu.py pins them).
-        inplace = t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad
+        inplace = t.device.type == "cpu" and t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad
         v = t if inplace else torch.empty(shape, dtype=torch.float32)
 
         def randn_():

@@ -2,7 +2,9 @@
 // resize (align_corners=True) with fused skip add.  See include/ada_hip.h for the reference call sites.
 // All of them move each byte once with 16-byte (fp32) / 8-byte (operand) accesses; row statistics use
 // wavefront shuffles only (one wave per row, no LDS).
+#include <atomic>
 #include <mutex>
+#include <stdlib.h>
 #include "ada_common.h"
 
 namespace {
@@ -48,6 +50,17 @@ ADA_DEV float wave_sum(float v) {
     return v;
 }
 
+template <int LPR>
+ADA_DEV float row_sum(float v) {      // sum over the LPR lanes that hold one row
+    if constexpr (LPR == 64) v += __shfl_xor(v, 32);
+    if constexpr (LPR == 64) v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
 ADA_DEV long pad_row(uint32_t m, int h, int w, FastDiv dW, FastDiv dHW) {
     uint32_t b, rem, y, x;
     fast_divmod(m, dHW, b, rem);
@@ -86,10 +99,16 @@ struct LnArgs {
     int identity;            // 1: no normalisation (y = x): the kernel is then the un-shuffle / re-layout pass of a sub-pixel convolution's output
 };
 
+// LPR = lanes per row.  64: one wave per row (rows of 1024-1536 floats: 4-6 float4 per lane in flight).  16: a quarter wave per row, four rows per wave -- the
+// head's channel LayerNorms run over 256 / 512-wide pixel rows, where one wave per row has a single 1 KB load in flight and the launch stopped at
+// 3.1-3.7 TB/s; with four rows per wave every lane keeps 4-8 float4 in flight and the reductions stay inside a 16-lane DPP row.
+template <int LPR>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
-    const int lane = threadIdx.x & 63;
-    const int ro = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ro >= p.rows_out) return;
+    constexpr int RPW = 64 / LPR;                       // rows per wave
+    constexpr int MAXC = LPR == 64 ? LN_MAX_CHUNKS : 8;  // float4 chunks per lane: dim <= 1536 / 512
+    const int lane = threadIdx.x & (LPR - 1);
+    const int ro = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + ((threadIdx.x & 63) / LPR);
+    if (ro >= p.rows_out) return;                        // (the reductions below only exchange between the LPR lanes of one row)
     long in_row = ro;
     if (p.group_in > 0) {
         uint32_t g, w;
@@ -120,11 +139,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
             tapb = p.tap_bias + (long)phase * p.dim * 9;
         }
     }
-    float4 v[LN_MAX_CHUNKS];
+    float4 v[MAXC];
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
-        const int c = lane + 64 * i;
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + LPR * i;
         if (c < nchunk) {
             v[i] = src[c];
             if (ring) {   // wave-uniform, ~2 % of the rows
@@ -137,25 +156,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    float mean = wave_sum(s) / (float)p.dim;
+    float mean = row_sum<LPR>(s) / (float)p.dim;
     float q = 0.0f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
-        const int c = lane + 64 * i;
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + LPR * i;
         if (c < nchunk) {
             const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
             q += (a * a + b * b) + (cc * cc + d * d);
         }
     }
-    float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.dim + p.eps);
+    float rstd = 1.0f / sqrtf(row_sum<LPR>(q) / (float)p.dim + p.eps);
     if (p.identity) { mean = 0.0f; rstd = 1.0f; }
     long orow = ro;
     if (p.out_op && p.map_op == ADA_MAP_PAD) orow = pad_row((uint32_t)ro, p.map_h, p.map_w, p.dMapW, p.dMapHW);
     const float4* w4 = (const float4*)p.weight;
     const float4* b4 = (const float4*)p.bias;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
-        const int c = lane + 64 * i;
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + LPR * i;
         if (c < nchunk) {
             float4 y = v[i];
             if (!p.identity) {
@@ -185,8 +204,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
         const float4* w24 = (const float4*)p.weight2;
         const float4* b24 = (const float4*)p.bias2;
 #pragma unroll
-        for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
-            const int c = lane + 64 * i;
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + LPR * i;
             if (c < nchunk) {
                 const float4 w = w24[c], bb = b24[c];
                 float4 y;
@@ -626,6 +645,8 @@ extern "C" int ada_rowstats_finalize(const float* partials, int32_t rows, int32_
     return ada_check_launch("ada_rowstats_finalize");
 }
 
+static std::atomic<int> g_ln_lpr{[]() { const char* e = getenv("ADA_LN_LPR"); return e ? atoi(e) : 0; }()};   // experiment switch: 64 = always one wave per row
+
 extern "C" int ada_layernorm_ex(const ada_layernorm_args* a, void* stream) {
     ADA_REQUIRE(a != nullptr, ADA_EINVAL, "ada_layernorm: null args");
     const int rows_out = a->rows_out, dim = a->dim;
@@ -666,7 +687,10 @@ extern "C" int ada_layernorm_ex(const ada_layernorm_args* a, void* stream) {
     } else {
         ADA_REQUIRE(!a->tap_bias, ADA_EINVAL, "ada_layernorm: tap_bias without unshuffle_s");
     }
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows_out + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    if (dim <= 512 && g_ln_lpr.load(std::memory_order_relaxed) != 64)     // a quarter wave per row (the kernel's comment); ADA_LN_LPR=64 keeps one wave per row (A/B)
+        hipLaunchKernelGGL(layernorm_kernel<16>, dim3((rows_out + 15) / 16), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<64>, dim3((rows_out + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     return ada_check_launch("ada_layernorm_fwd");
 }
 

@@ -42,6 +42,9 @@ enum { EPI_STD = 0, EPI_GELU = 1, EPI_SHUFFLE = 2, EPI_SWIGLU = 3, EPI_TAIL = 4 
 #ifndef ADA_EPI_WT
 #define ADA_EPI_WT 0          // experiment: 1 = the fp32 residual-stream stores of the proj / fc2 epilogues are write-through (sc1) also without a LayerNorm tail
 #endif
+#ifndef ADA_GELU_PACKED
+#define ADA_GELU_PACKED 1     // the GELU epilogue's polynomial on v_pk_fma_f32 (gelu_erf2); 0 = scalar (A/B build)
+#endif
 #ifndef ADA_LN_TAIL_PLAIN
 #define ADA_LN_TAIL_PLAIN 0   // experiment switch of the LayerNorm tail's reader: 1 = agent-scope acquire + plain loads, 0 = sc1 loads
 #endif
@@ -137,6 +140,38 @@ ADA_DEV float gelu_erf(float x) {
     q = __builtin_fmaf(q, a, 9.9999958888e-01f);
     const float tail = __builtin_amdgcn_exp2f(-q);   // Phi(-|x|)
     return __builtin_fmaf(-a, tail, __builtin_fmaxf(x, 0.0f));
+}
+
+// The same GELU on a PAIR of values: the six polynomial steps and the final product run as packed fp32 operations (v_pk_fma_f32: two lanes' worth of
+// FMAs per issue slot).  Packed fp32 is an anti-lever BESIDE MFMAs (MI355X_MICROARCH.md; the file is built without SLP vectorisation for that reason),
+// but the GELU epilogue runs when the tile's MFMAs are done: all eight waves of the CU are in their epilogues together and the matrix pipe is idle,
+// so here the packed form simply halves the FMA issue slots (per element: 1 min + 3 packed FMA halves... ~6.5 slots + the exp2 instead of ~10 + exp2).
+// Bit-identical to gelu_erf: the same fp32 operations in the same order on each element.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+ADA_DEV void gelu_erf2(float& x0, float& x1) {
+    const f32x2_t x = {x0, x1};
+    const f32x2_t a = {__builtin_fminf(__builtin_fabsf(x0), 12.0f), __builtin_fminf(__builtin_fabsf(x1), 12.0f)};
+    f32x2_t q = {-3.2904290173e-05f, -3.2904290173e-05f};
+    q = __builtin_elementwise_fma(q, a, (f32x2_t){7.6214928455e-04f, 7.6214928455e-04f});
+    q = __builtin_elementwise_fma(q, a, (f32x2_t){-8.0387993652e-03f, -8.0387993652e-03f});
+    q = __builtin_elementwise_fma(q, a, (f32x2_t){5.3315321524e-02f, 5.3315321524e-02f});
+    q = __builtin_elementwise_fma(q, a, (f32x2_t){4.5887145819e-01f, 4.5887145819e-01f});
+    q = __builtin_elementwise_fma(q, a, (f32x2_t){1.1511568259e+00f, 1.1511568259e+00f});
+    q = __builtin_elementwise_fma(q, a, (f32x2_t){9.9999958888e-01f, 9.9999958888e-01f});
+    const f32x2_t tail = {__builtin_amdgcn_exp2f(-q[0]), __builtin_amdgcn_exp2f(-q[1])};
+    const f32x2_t pos = {__builtin_fmaxf(x0, 0.0f), __builtin_fmaxf(x1, 0.0f)};
+    const f32x2_t r = __builtin_elementwise_fma(-a, tail, pos);
+    x0 = r[0];
+    x1 = r[1];
+    (void)x;
+}
+ADA_DEV void gelu_erf4(float4& v) {
+#if ADA_GELU_PACKED
+    gelu_erf2(v.x, v.y);
+    gelu_erf2(v.z, v.w);
+#else
+    gelu_erf4(v);
+#endif
 }
 
 // SiLU of the SwiGLU gate (reference swiglu_ffn.py:31): t * sigmoid(t), the division as one v_rcp (1 ulp) instead of the IEEE sequence
@@ -722,8 +757,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                             v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
                         }
                         if constexpr (EPI == EPI_GELU) {
-                            v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
-                            v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
+                            gelu_erf4(v0);
+                            gelu_erf4(v1);
                         }
                         if (has_gamma) {
                             v0.x *= g0.x; v0.y *= g0.y; v0.z *= g0.z; v0.w *= g0.w;
@@ -793,7 +828,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                     float4 v = *(const float4*)(slab + (k * RPI + rsub) * SW + 4 * cg);
                     v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                     if constexpr (EPI == EPI_GELU) {
-                        v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                        gelu_erf4(v);
                     }
                     v.x = v.x * gamma4.x + rcur[k].x; v.y = v.y * gamma4.y + rcur[k].y;
                     v.z = v.z * gamma4.z + rcur[k].z; v.w = v.w * gamma4.w + rcur[k].w;
@@ -884,8 +919,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                         v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
                     }
                     if constexpr (EPI == EPI_GELU) {
-                        v0.x = gelu_erf(v0.x); v0.y = gelu_erf(v0.y); v0.z = gelu_erf(v0.z); v0.w = gelu_erf(v0.w);
-                        v1.x = gelu_erf(v1.x); v1.y = gelu_erf(v1.y); v1.z = gelu_erf(v1.z); v1.w = gelu_erf(v1.w);
+                        gelu_erf4(v0);
+                        gelu_erf4(v1);
                     }
                     v0.x *= g0.x; v0.y *= g0.y; v0.z *= g0.z; v0.w *= g0.w;
                     v1.x *= g1.x; v1.y *= g1.y; v1.z *= g1.z; v1.w *= g1.w;
@@ -983,7 +1018,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 float4 v = *(const float4*)(slab + row * SW + 4 * cg);
                 v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                 if constexpr (EPI == EPI_GELU) {
-                    v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                    gelu_erf4(v);
                 }
                 v.x = v.x * gamma4.x + rcur[k].x; v.y = v.y * gamma4.y + rcur[k].y;
                 v.z = v.z * gamma4.z + rcur[k].z; v.w = v.w * gamma4.w + rcur[k].w;

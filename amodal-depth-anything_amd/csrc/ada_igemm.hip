@@ -22,6 +22,7 @@
 // Epilogue.  Accumulators are transposed through LDS (wave-private 32-row slabs, fp32) so that every lane then
 // owns 4 consecutive columns of a row: bias / LayerScale / residual / activation run on float4, and the
 // fp32 (16 B) and operand-typed (8 B) stores are contiguous 128-256 B row segments.
+#include <math.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <atomic>
@@ -41,9 +42,6 @@ enum { EPI_STD = 0, EPI_GELU = 1, EPI_SHUFFLE = 2, EPI_SWIGLU = 3, EPI_TAIL = 4 
 #endif
 #ifndef ADA_EPI_WT
 #define ADA_EPI_WT 0          // experiment: 1 = the fp32 residual-stream stores of the proj / fc2 epilogues are write-through (sc1) also without a LayerNorm tail
-#endif
-#ifndef ADA_GELU_PACKED
-#define ADA_GELU_PACKED 1     // the GELU epilogue's polynomial on v_pk_fma_f32 (gelu_erf2); 0 = scalar (A/B build)
 #endif
 #ifndef ADA_LN_TAIL_PLAIN
 #define ADA_LN_TAIL_PLAIN 0   // experiment switch of the LayerNorm tail's reader: 1 = agent-scope acquire + plain loads, 0 = sc1 loads
@@ -142,36 +140,14 @@ ADA_DEV float gelu_erf(float x) {
     return __builtin_fmaf(-a, tail, __builtin_fmaxf(x, 0.0f));
 }
 
-// The same GELU on a PAIR of values: the six polynomial steps and the final product run as packed fp32 operations (v_pk_fma_f32: two lanes' worth of
-// FMAs per issue slot).  Packed fp32 is an anti-lever BESIDE MFMAs (MI355X_MICROARCH.md; the file is built without SLP vectorisation for that reason),
-// but the GELU epilogue runs when the tile's MFMAs are done: all eight waves of the CU are in their epilogues together and the matrix pipe is idle,
-// so here the packed form simply halves the FMA issue slots (per element: 1 min + 3 packed FMA halves... ~6.5 slots + the exp2 instead of ~10 + exp2).
-// Bit-identical to gelu_erf: the same fp32 operations in the same order on each element.
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-ADA_DEV void gelu_erf2(float& x0, float& x1) {
-    const f32x2_t x = {x0, x1};
-    const f32x2_t a = {__builtin_fminf(__builtin_fabsf(x0), 12.0f), __builtin_fminf(__builtin_fabsf(x1), 12.0f)};
-    f32x2_t q = {-3.2904290173e-05f, -3.2904290173e-05f};
-    q = __builtin_elementwise_fma(q, a, (f32x2_t){7.6214928455e-04f, 7.6214928455e-04f});
-    q = __builtin_elementwise_fma(q, a, (f32x2_t){-8.0387993652e-03f, -8.0387993652e-03f});
-    q = __builtin_elementwise_fma(q, a, (f32x2_t){5.3315321524e-02f, 5.3315321524e-02f});
-    q = __builtin_elementwise_fma(q, a, (f32x2_t){4.5887145819e-01f, 4.5887145819e-01f});
-    q = __builtin_elementwise_fma(q, a, (f32x2_t){1.1511568259e+00f, 1.1511568259e+00f});
-    q = __builtin_elementwise_fma(q, a, (f32x2_t){9.9999958888e-01f, 9.9999958888e-01f});
-    const f32x2_t tail = {__builtin_amdgcn_exp2f(-q[0]), __builtin_amdgcn_exp2f(-q[1])};
-    const f32x2_t pos = {__builtin_fmaxf(x0, 0.0f), __builtin_fmaxf(x1, 0.0f)};
-    const f32x2_t r = __builtin_elementwise_fma(-a, tail, pos);
-    x0 = r[0];
-    x1 = r[1];
-    (void)x;
-}
+// (Round 5: the polynomial on packed fp32 -- v_pk_fma_f32 on pairs of elements, half the FMA issue slots, bit-identical -- measured NEUTRAL: fc1 + GELU
+// 405.6 us against 402-412 scalar; with the GELU compiled out the launch takes 361 us, so the activation costs 44 us of VALU work that is not bound
+// by FMA issue.  profiles/r05_f_ln_quarter_wave_and_packed_gelu.txt)
 ADA_DEV void gelu_erf4(float4& v) {
-#if ADA_GELU_PACKED
-    gelu_erf2(v.x, v.y);
-    gelu_erf2(v.z, v.w);
-#else
-    gelu_erf4(v);
-#endif
+    v.x = gelu_erf(v.x);
+    v.y = gelu_erf(v.y);
+    v.z = gelu_erf(v.z);
+    v.w = gelu_erf(v.w);
 }
 
 // SiLU of the SwiGLU gate (reference swiglu_ffn.py:31): t * sigmoid(t), the division as one v_rcp (1 ulp) instead of the IEEE sequence
@@ -1217,6 +1193,17 @@ static inline double tile_time(long M, long N, int bm, int bn, int occ, double e
     if (tiles <= slots) return ((tiles + 255) / 256) * t;   // partially filled single round
     return (double)((tiles + slots - 1) / slots) * occ * t;
 }
+// Second estimate for the co-resident small tiles (round 5, profiles/r05_e_config2_shapes.txt): the busiest CU runs ceil(tiles / 256) of them whatever
+// the residency -- the slot-rounded model above charges 2064 tiles of 128x128 five rounds of 512 slots (2560) where the CUs see 8.06 -> 9 tiles each --
+// with a main-loop efficiency that FALLS with K (fitted on the ViT-B bs=8 and ViT-L bs=32 sweeps: 128x128 0.89 / 0.70 / 0.58 of the 256x256 tile at
+// K = 768 / 2304 / 9216): short-K launches with few 256x256 tiles (ViT-B at bs=8: 129 tiles on 256 CUs) go to the small tiles, long-K ones never do.
+static inline double tile_time_cu(long M, long N, long K, int bm, int bn, double e0, double slope, double emax) {
+    const long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    const double lg = K > 512 ? log2((double)K / 512.0) : 0.0;
+    double eff = e0 - slope * lg;
+    eff = eff > emax ? emax : (eff < 0.45 ? 0.45 : eff);
+    return (double)((tiles + 255) / 256) * bm * bn / eff;
+}
 
 // main loop of the 256x256 tile: variant 16 forces the hand-scheduled 4-wave loop, 4 the single-barrier 8-wave loop; 0 (default) picks the
 // 4-wave loop where its main loop outweighs its slower prologue / epilogue (measured: k-loops of >= 128 k-tiles)
@@ -1228,16 +1215,22 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force) {
     int cfg;
     if (d.N <= 32) cfg = 0;
     else if (d.N <= 64) cfg = 1;
-    else if (d.N <= 128) cfg = 4;   // two co-resident 128x128 workgroups per CU: -12 % vs the 512x128 / 256x128 tiles at every batch size
-    else {
+    else if (d.N <= 128) {
+        // two co-resident 128x128 workgroups per CU: -12 % vs the 512x128 / 256x128 tiles at every batch size -- unless that leaves more than half of
+        // the CUs without a tile: then 128x64 tiles (ViT-B head at bs <= 8, single images: -25 ... -33 % per launch, profiles/r05_e_*)
+        cfg = (EPI != EPI_SWIGLU && ((long)(d.M + 127) / 128) <= 128) ? 1 : 4;
+    } else {
         // large problems: the 256x256 tile (best MFMA efficiency); small ones (single images, ViT-S/B at small batch)
         // would leave most CUs idle with it, so pick the tile that minimises the quantised time estimate
         cfg = 3;
         double best = tile_time(d.M, d.N, 256, 256, 1, 1.0);
         // relative main-loop efficiencies re-fitted after the move to 16x16x32 MFMAs (tools/autotune_shapes.py at B = 1 and 4:
         // the 128x64 tile with three co-resident workgroups wins more of the small problems than it used to)
-        const double t2 = tile_time(d.M, d.N, 256, 128, 1, 0.72), t4 = tile_time(d.M, d.N, 128, 128, 2, 0.85),
-                     t1 = tile_time(d.M, d.N, 128, 64, 3, 0.80);
+        const long Kt = d.K;     // k-loop length (all taps / split segments)
+        double t2 = tile_time(d.M, d.N, 256, 128, 1, 0.72), t4 = tile_time(d.M, d.N, 128, 128, 2, 0.85), t1 = tile_time(d.M, d.N, 128, 64, 3, 0.80);
+        const double t4c = tile_time_cu(d.M, d.N, Kt, 128, 128, 0.95, 0.095, 0.90), t1c = tile_time_cu(d.M, d.N, Kt, 128, 64, 0.90, 0.10, 0.85);
+        if (t4c < t4) t4 = t4c;     // either estimate may make the case for the small tile
+        if (t1c < t1) t1 = t1c;
         if (t2 < 0.95 * best) { best = t2; cfg = 2; }
         if (t4 < 0.95 * best) { best = t4; cfg = 4; }
         if (EPI != EPI_SWIGLU && t1 < 0.90 * best) { best = t1; cfg = 1; }   // the small tile loses on long k-loops at equal estimate

@@ -368,17 +368,18 @@ class PackedWeights:
         self.oc1c = None     # output_conv1 composed with refinenet1.out_conv, one 1x1 per tap: [9 * half, Fp] (+ the bias each tap map carries)
         half_ = self.features // 2
         if OC1_COMMUTE and "oc1" not in self.split and "out0" not in self.split and half_ in (32, 64, 128):
-            w1 = f32(s + "output_conv1.weight").double()                         # [half, F, 3, 3]
-            wo_ = f32(s + "refinenet1.out_conv.weight").double().reshape(self.features, self.features)   # [F(cm), F(ci)]
-            bo_ = f32(s + "refinenet1.out_conv.bias").double()
+            from .functional import compose_f32
+            w1 = f32(s + "output_conv1.weight")                                  # [half, F, 3, 3]
+            wo_ = f32(s + "refinenet1.out_conv.weight").reshape(self.features, self.features)   # [F(cm), F(ci)]
+            bo_ = f32(s + "refinenet1.out_conv.bias")
             wt_ = w1.permute(2, 3, 0, 1).reshape(9 * half_, self.features)       # rows (tap, co), columns cm
             # [w_hi | w_lo] (ada_igemm a_wrap): rounding the COMPOSED matrix to the operand type once is not harmless -- its error acts on the
             # activation's large common-mode part coherently over all taps and positions and survives the resizes and convolutions behind it
             # (oracle study: 5.3e-4 at the output of ViT-B from this rounding alone, against 1.0e-4 / 0.9e-4 for the two factors rounded
             # separately; profiles/r04_g_output_conv1_commute.txt).  K = 2 * 256 on a GEMM that is bound by its 1.6 GB of output anyway.
-            wc_ = (wt_ @ wo_).float()
+            wc_ = compose_f32(wt_, wo_.t())       # the library's own GEMM in split precision (functional.compose_f32); W_t b_out is a reduction
             wc_hi = wc_.to(op)
-            self.oc1c = dict(w=torch.cat([wc_hi, (wc_ - wc_hi.float()).to(op)], dim=1).contiguous(), b=(wt_ @ bo_).float().contiguous())
+            self.oc1c = dict(w=torch.cat([wc_hi, (wc_ - wc_hi.float()).to(op)], dim=1).contiguous(), b=(wt_.double() * bo_.double()[None, :]).sum(1).float().contiguous())
         self.oc2_w, self.oc2_b = conv3(f32(s + "output_conv2.0.weight"), "oc2"), f32(s + "output_conv2.0.bias")
         self.tail_w = f32(s + "output_conv2.2.weight").reshape(-1).contiguous()
         self.tail_b = float(f32(s + "output_conv2.2.bias").reshape(-1)[0].item())

@@ -10,6 +10,7 @@ cast) only; every contraction, normalisation, softmax and resample runs in a HIP
 from __future__ import annotations
 
 import torch
+import torch.nn.functional as F
 
 from . import (A_CONV3, ACT_NONE, ACT_RELU, ACT_SIGMOID, EP_BIAS, EP_GELU, EP_RELU_OP, EP_RESIDUAL, EP_SWIGLU, EP_TAIL,
                MAP_PAD, MAP_SHUFFLE, HipExtError)
@@ -238,11 +239,13 @@ def subpixel_merge(wt, bt, w3, b3, s):
     Ci, Cm = wt.shape[:2]
     Co = w3.shape[0]
     dev = wt.device
-    Wm = torch.zeros(s, s, Co, 9, Ci, dtype=torch.float64, device=dev)
-    tb = torch.zeros(s, s, Co, 9, dtype=torch.float64, device=dev)
+    # every product W3[:, :, ty, tx] @ Wt[:, :, qy, qx]^T in ONE launch: rows (ty, tx, co), columns (qy, qx, ci) -- compose_f32 (ada_igemm in split
+    # precision: ~1e-7 relative, far below the fp16 rounding the packed result gets); the sums over the fine taps that share a coarse tap are adds
+    P = compose_f32(w3.permute(2, 3, 0, 1).reshape(9 * Co, Cm), wt.permute(2, 3, 0, 1).reshape(s * s * Ci, Cm)).view(3, 3, Co, s, s, Ci)
+    Wm = torch.zeros(s, s, Co, 9, Ci, dtype=torch.float32, device=dev)
+    tb = torch.zeros(s, s, Co, 9, dtype=torch.float32, device=dev)
     masks = [0] * (s * s)
-    wt64, w364 = wt.double(), w3.double()
-    bt64 = None if bt is None else bt.double()
+    tbias = None if bt is None else (w3.double() * bt.double().view(1, Cm, 1, 1)).sum(1).float()     # [Co, 3, 3]: W3[:, :, ty, tx] @ bt (a reduction, not a GEMM)
     for py in range(s):
         for px in range(s):
             for ty in range(3):
@@ -251,14 +254,35 @@ def subpixel_merge(wt, bt, w3, b3, s):
                     dy, dx = vy // s, vx // s              # floor: -1 -> -1, s -> 1
                     qy, qx = vy - s * dy, vx - s * dx
                     t = (dy + 1) * 3 + (dx + 1)
-                    Wm[py, px, :, t, :] += w364[:, :, ty, tx] @ wt64[:, :, qy, qx].T
-                    if bt64 is not None:
-                        tb[py, px, :, t] += w364[:, :, ty, tx] @ bt64
+                    Wm[py, px, :, t, :] += P[ty, tx, :, qy, qx, :]
+                    if tbias is not None:
+                        tb[py, px, :, t] += tbias[:, ty, tx]
                     masks[py * s + px] |= 1 << t
     bias = tb.sum(-1)
     if b3 is not None:
-        bias = bias + b3.double().view(1, 1, Co)
-    return (Wm.reshape(s * s * Co, 9, Ci).float(), bias.reshape(-1).float().contiguous(), tb.reshape(s * s * Co, 9).float().contiguous(), masks)
+        bias = bias + b3.float().view(1, 1, Co)
+    return (Wm.reshape(s * s * Co, 9, Ci).contiguous(), bias.reshape(-1).contiguous(), tb.reshape(s * s * Co, 9).contiguous(), masks)
+
+
+def compose_f32(a, b):
+    """a [M, K] @ b [N, K]^T -> [M, N] fp32 for WEIGHT composition at pack time (sub-pixel merges, output_conv1 o out_conv), on the library's own GEMM:
+    both factors are carried as hi + lo operand pairs -- a as [hi | lo] rows, b packed [hi | hi | lo] -- and one ada_igemm over the three k segments
+    evaluates a_hi b_hi + a_lo b_hi + a_hi b_lo with fp32 accumulation (error ~ 2^-22 |a||b| per term; the result is rounded to the operand type, or
+    to a hi / lo pair, right afterwards).  No vendor BLAS anywhere in the package, pack time included (round 4 composed with torch fp64 matmuls)."""
+    _need_cuda(a, "compose_f32 input")
+    op = operand_dtype()
+    M, K = a.shape
+    N = b.shape[0]
+    kp, np_ = _r64(K), (N + 3) // 4 * 4
+    a32 = F.pad(a.detach().float(), (0, kp - K))
+    b32 = F.pad(b.detach().float(), (0, kp - K, 0, np_ - N))
+    a_hi = a32.to(op)
+    b_hi = b32.to(op)
+    A = torch.cat([a_hi, (a32 - a_hi.float()).to(op)], dim=1).contiguous()
+    Wp = torch.cat([b_hi, b_hi, (b32 - b_hi.float()).to(op)], dim=1).contiguous()
+    out = torch.empty(M, np_, dtype=torch.float32, device=a.device)
+    k_igemm(M=M, N=np_, K=3 * kp, A=A, lda=2 * kp, a_dup_seg=kp, W=Wp, flags=0, out_f32=out, ldo_f32=np_)
+    return out[:, :N] if np_ != N else out
 
 
 def residual_conv_unit(x, w1, b1, w2, b2):

@@ -169,7 +169,8 @@ def test_subpixel_conv_matches_conv_of_conv_transpose(hip, forced_tile, s, Ci, C
     w3 = _rand(Co, Cm, 3, 3, seed=34) * (9 * Cm) ** -0.5
     b3 = _rand(Co, seed=35)
     ref = F.conv2d(F.conv_transpose2d(x, wt, bt, stride=s), w3, b3, padding=1)          # fp32, [B, Co, sH, sW]
-    wm, bias, tapb, masks = subpixel_merge(wt, bt, w3, b3, s)
+    wm, bias, tapb, masks = subpixel_merge(wt.to(DEV), bt.to(DEV), w3.to(DEV), b3.to(DEV), s)     # composed on the device (functional.compose_f32)
+    wm, bias, tapb = wm.cpu(), bias.cpu(), tapb.cpu()
     assert sum(bin(m).count("1") for m in masks) == (36 if s == 4 else 16)
     wp = torch.zeros(s * s * Co, 9, cp)
     wp[..., :Ci] = wm
@@ -287,6 +288,20 @@ def test_tapsum_resize_right_edge_halo_column_reads_staged_data(hip, wo):
         assert torch.isfinite(got).all(), f"wo={wo}: non-finite output at the right edge"
         err = float((got[..., -2:] - ref[..., -2:]).abs().mean() / ref[..., -2:].abs().mean())
         assert err < 3e-3, f"wo={wo} {tdt}: last two columns rel-L1 {err:.2e}"
+
+
+@pytest.mark.parametrize("M,N,K", [(9 * 256, 16 * 256, 256), (9 * 96, 4 * 96, 96), (1152, 256, 256), (7, 5, 3)])
+def test_compose_f32_weight_products(hip, M, N, K):
+    """functional.compose_f32 (weight composition at pack time: sub-pixel merges, output_conv1 o out_conv) on the library's own split-precision GEMM
+    against the fp64 product: ~fp32 accuracy, any M / N / K (padded internally)."""
+    from hip_ext.functional import compose_f32
+    a, b = _rand(M, K, seed=301) * K ** -0.5, _rand(N, K, seed=302) * K ** -0.5
+    got = compose_f32(a.to(DEV), b.to(DEV)).cpu()
+    ref = a.double() @ b.double().T
+    assert got.shape == (M, N)
+    err = float((got.double() - ref).abs().max() / ref.abs().max())
+    print(f"compose_f32 {M}x{N}x{K}: max abs error / max |ref| = {err:.2e}")
+    assert err < (2e-6 if _op(hip) == torch.float16 else 1e-4)     # dropped lo x lo terms and the lo halves' own rounding: ~2^-22 each
 
 
 @pytest.mark.parametrize("G,rows,N,K,cfg,gelu", [(3, 50, 64, 128, -1, True), (5, 1369, 384, 384, -1, True), (2, 300, 256, 192, 3, False), (4, 77, 128, 64, 4, True), (7, 9, 96, 128, 1, False)])

@@ -203,3 +203,19 @@ def make_inputs(batch: int, height: int = 518, width: int = 518, seed: int = 0, 
         ww = int(torch.randint(width // 8, width // 2, (1,), generator=g))
         mask[b, :, y0:y0 + hh, x0:x0 + ww] = 1.0
     return x.to(device), guide_rgb.to(device), mask.to(device), obs.to(device)
+
+
+def centred_final_bias(encoder: str, repo_root: str):
+    """The logit-centring value of ``output_conv2.2.bias`` that the reference fixtures of the seed-0 fill carry for AmodalDAv2 (guide mask+observation):
+    tests/golden/<encoder>_518.npz metadata.  Tools that time the synthetic model use it so that the depth maps span (0, 1) -- the un-centred fill's maps
+    sit near 0, where the sigmoid heads' precision ladder (rightly) re-runs the head in split precision and the timing is not the default path's."""
+    import json
+    import os
+
+    import numpy as np
+    name = {"vits": "vits_518", "vitb": "vitb_518", "vitl": "vitl_518"}.get(encoder)
+    path = os.path.join(repo_root, "tests", "golden", f"{name}.npz") if name else None
+    if not path or not os.path.exists(path):
+        return None
+    meta = json.loads(str(np.load(path)["meta"]))
+    return meta["final_bias_key"], float(meta["final_bias"])

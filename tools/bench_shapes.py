@@ -25,10 +25,13 @@ def main():
     ap.add_argument("--encoder", default="vitl")
     args = ap.parse_args()
     from src.models import get_model
-    from src.util.synth_weights import fill_state_dict_, make_inputs
+    from src.util.synth_weights import centred_final_bias, fill_state_dict_, make_inputs
     m = get_model("AmodalDAv2", guide_type="mask+observation", loss_stategy="x", encoder=args.encoder, pretrained=False).eval()
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     fill_state_dict_(sd, 0)
+    cb = centred_final_bias(args.encoder, ROOT)
+    if cb:
+        sd[cb[0]] = torch.full_like(sd[cb[0]], cb[1])
     m.load_state_dict(sd)
     m = m.cuda()
     x, _, mask, obs = make_inputs(args.batch, 518, 518, 0, device="cuda")

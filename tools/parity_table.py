@@ -23,7 +23,7 @@ def main():
             c = load_golden(n)[1]["case"]
             if c["kind"] == "amodal" and "ssi" not in c["loss"] and c["encoder"] in ("vitb", "vitl"):
                 names.append(n)
-    print(f"{'fixture':28s} {'mean':>6s} {'r':>6s} | {'rung 1':>9s} {'default':>9s} {'esc':>4s} | {'head split':>10s} {'+enc deep':>10s}")
+    print(f"{'fixture':28s} {'mean':>6s} {'r':>6s} {'tokdiv':>6s} | {'rung 1':>9s} {'default':>9s} {'esc':>4s} | {'head split':>10s} {'+enc deep':>10s}")
     for name in names:
         gold, meta = load_golden(name)
         case = meta["case"]
@@ -47,6 +47,11 @@ def main():
         enc.precision_ladder = None
         res["def"] = run()
         eng = enc._engine()
+        # token diversity of the final tap (torch ops, study only): sum_c Var_p(t) / sum_c E_p[t^2] per image -- ~0 when every patch token is the same (constant inputs)
+        ws = next(iter(eng._ws.values()))
+        Dm = eng.w.dim
+        t3 = ws.taps[3][:, :Dm].float().view(ws.B, -1, Dm)
+        div = float((t3.var(dim=1, unbiased=False).sum(-1) / (t3 * t3).mean(dim=1).sum(-1)).min())
         ratio = eng.last_ratio
         rmax = float(ratio.max()) if ratio is not None else float("nan")
         nesc = int((ratio > eng.ladder["r"]).sum()) if ratio is not None else 0
@@ -55,7 +60,7 @@ def main():
         enc.encoder_precision = 8 if case["encoder"] in ("vitl", "vitg") else 4
         res["hse"] = run()
         enc.head_precision, enc.encoder_precision = "auto", "auto"
-        print(f"{name:28s} {meta['out_mean']:6.3f} {rmax:6.3f} | {res['r1'][1]:9.2e} {res['def'][1]:9.2e} {nesc:4d} | {res['hs'][1]:10.2e} {res['hse'][1]:10.2e}", flush=True)
+        print(f"{name:28s} {meta['out_mean']:6.3f} {rmax:6.3f} {div:6.3f} | {res['r1'][1]:9.2e} {res['def'][1]:9.2e} {nesc:4d} | {res['hs'][1]:10.2e} {res['hse'][1]:10.2e}", flush=True)
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@ for p in (ROOT, os.path.join(ROOT, "amodal-depth-anything_amd")):
 import torch
 from src.models import get_model
 from src.models.amodalsynthdrive.depth_anything_v2_raw.dpt import DepthAnythingV2 as Raw
-from src.util.synth_weights import fill_state_dict_, make_inputs
+from src.util.synth_weights import centred_final_bias, fill_state_dict_, make_inputs
 
 
 def timeit(fn, n=3):
@@ -22,18 +22,21 @@ def timeit(fn, n=3):
     return out, (time.perf_counter() - t0) / n
 
 
-def synth(m):
+def synth(m, encoder=None):
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     fill_state_dict_(sd, 0)
+    cb = centred_final_bias(encoder, ROOT) if encoder else None     # sigmoid model: centred logits (the default, first-rung path is what is timed)
+    if cb:
+        sd[cb[0]] = torch.full_like(sd[cb[0]], cb[1])
     m.load_state_dict(sd)
     return m.cuda().eval()
 
 
 with torch.no_grad():
-    m = synth(get_model("AmodalDAv2", guide_type="mask+observation", loss_stategy="entire_target_object", encoder="vitb", pretrained=False))
+    m = synth(get_model("AmodalDAv2", guide_type="mask+observation", loss_stategy="entire_target_object", encoder="vitb", pretrained=False), "vitb")
     x, _, mask, obs = make_inputs(8, 518, 518, 0, device="cuda")
     out, dt = timeit(lambda: m(x, guide_mask=mask, observation=obs))
-    print(f"config 2  ViT-B bs=8 518x518: {8 / dt:.1f} images/s ({dt * 1e3:.1f} ms/step, {8 / dt * 396.26 / 1e3:.0f} TFLOP/s), finite={bool(torch.isfinite(out).all())}, range=({float(out.min()):.3f},{float(out.max()):.3f})")
+    print(f"config 2  ViT-B bs=8 518x518: {8 / dt:.1f} images/s ({dt * 1e3:.1f} ms/step, {8 / dt * 396.26 / 1e3:.0f} TFLOP/s), finite={bool(torch.isfinite(out).all())}, range=({float(out.min()):.3f},{float(out.max()):.3f}), mean {float(out.mean()):.3f}, ladder re-ran {m.encoder._engine().escalated} images")
     del m, out
     torch.cuda.empty_cache()
     r = synth(Raw(encoder="vitg", features=384, out_channels=[1536] * 4))

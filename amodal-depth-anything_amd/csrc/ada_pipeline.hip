@@ -65,6 +65,45 @@ __global__ __launch_bounds__(1024) void depth_stats_kernel(const float* __restri
     }
 }
 
+// Token diversity of one encoder tap: per image  sum_c Var_p(t[p, c])  and  sum_c E_p[t[p, c]^2]  over the image's patch tokens p (rows) and the feature
+// columns c.  Their ratio is ~0.3-0.5 for images and ~0.02 for constant inputs (every patch token equal up to its position): there the head's operand
+// rounding errors add coherently over positions and the single-precision head's relative L1 doubles -- the second trigger of the engine's precision
+// ladder (the first, ada_depth_stats_fwd, only sees the output).  grid (column chunks of 64, batch); 256 threads = 64 columns x 4 row groups; every
+// workgroup writes (sum of the column variances, sum of the column mean squares) of its chunk: fixed order, no atomics.
+__global__ __launch_bounds__(256) void token_diversity_kernel(const op_t* __restrict__ tap, long ld, int rows_per_image, int dim, float* __restrict__ out) {
+    __shared__ float s1[4][64], s2[4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c, b = blockIdx.y;
+    const op_t* src = tap + (long)b * rows_per_image * ld + col;
+    float a = 0.0f, q = 0.0f;
+    if (col < dim)
+        for (int r = rg; r < rows_per_image; r += 4) {
+            const float v = (float)src[(long)r * ld];
+            a += v;
+            q += v * v;
+        }
+    s1[rg][c] = a;
+    s2[rg][c] = q;
+    __syncthreads();
+    if (rg == 0) {
+        a = (s1[0][c] + s1[1][c]) + (s1[2][c] + s1[3][c]);
+        q = (s2[0][c] + s2[1][c]) + (s2[2][c] + s2[3][c]);
+        const float inv = 1.0f / (float)rows_per_image;
+        const float mean = a * inv, msq = q * inv;
+        float var = col < dim ? __builtin_fmaxf(msq - mean * mean, 0.0f) : 0.0f;
+        float ms = col < dim ? msq : 0.0f;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            var += __shfl_xor(var, o);
+            ms += __shfl_xor(ms, o);
+        }
+        if (c == 0) {
+            out[((long)b * gridDim.x + blockIdx.x) * 2] = var;
+            out[((long)b * gridDim.x + blockIdx.x) * 2 + 1] = ms;
+        }
+    }
+}
+
 // norm = (d - min) / (max - min)   (reference infer.py:22);  obs = norm * 2 - 1   (infer.py:92)
 __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ in, const float* __restrict__ minmax, long n_per_image,
                                                         float* __restrict__ norm, float* __restrict__ obs) {
@@ -165,6 +204,13 @@ extern "C" int ada_depth_stats_fwd(const float* in, int32_t batch, int64_t n_per
     ADA_REQUIRE(batch > 0 && batch <= 65535 && n_per_image > 0 && chunks > 0 && chunks <= 1024, ADA_EINVAL, "ada_depth_stats_fwd: bad shape (batch=%d chunks=%d)", batch, chunks);
     hipLaunchKernelGGL(depth_stats_kernel, dim3(chunks, batch), dim3(1024), 0, (hipStream_t)stream, in, (long)n_per_image, sums);
     return ada_check_launch("ada_depth_stats_fwd");
+}
+
+extern "C" int ada_token_diversity_fwd(const void* tap, int64_t ld, int32_t batch, int32_t rows_per_image, int32_t dim, float* sums, void* stream) {
+    ADA_REQUIRE(tap && sums, ADA_EINVAL, "ada_token_diversity_fwd: null pointer");
+    ADA_REQUIRE(batch > 0 && batch <= 65535 && rows_per_image > 0 && dim > 0 && ld >= dim, ADA_EINVAL, "ada_token_diversity_fwd: bad shape (batch=%d rows=%d dim=%d ld=%ld)", batch, rows_per_image, dim, (long)ld);
+    hipLaunchKernelGGL(token_diversity_kernel, dim3((dim + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream, (const op_t*)tap, (long)ld, rows_per_image, dim, sums);
+    return ada_check_launch("ada_token_diversity_fwd");
 }
 
 extern "C" int ada_normalize_fwd(const float* in, const float* minmax, int32_t batch, int64_t n_per_image, float* norm, float* obs,

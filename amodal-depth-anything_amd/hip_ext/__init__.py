@@ -29,7 +29,7 @@ ACT_NONE, ACT_SIGMOID, ACT_RELU = 0, 1, 2
 EXPORTS = (
     "ada_abi_version", "ada_operand_dtype", "ada_last_error", "ada_igemm", "ada_attention_fwd",
     "ada_rowstats_finalize", "ada_pos_embed_resize", "ada_layernorm_fwd", "ada_layernorm_ex", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
-    "ada_minmax_fwd", "ada_depth_stats_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd", "ada_dpt_tail_fwd", "ada_tapsum_resize_fwd",
+    "ada_minmax_fwd", "ada_depth_stats_fwd", "ada_token_diversity_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd", "ada_dpt_tail_fwd", "ada_tapsum_resize_fwd",
     "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
     "ada_debug_set_timestamps", "ada_debug_set_attention_variant", "ada_debug_count_saturated",
 )
@@ -129,6 +129,8 @@ def load(path: Optional[str] = None):
     lib.ada_minmax_fwd.restype = c_int
     lib.ada_depth_stats_fwd.argtypes = [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]
     lib.ada_depth_stats_fwd.restype = c_int
+    lib.ada_token_diversity_fwd.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]
+    lib.ada_token_diversity_fwd.restype = c_int
     lib.ada_normalize_fwd.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]
     lib.ada_normalize_fwd.restype = c_int
     lib.ada_blend_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
@@ -363,6 +365,12 @@ def depth_stats(inp, sums):
     B = inp.shape[0]
     _check(load().ada_depth_stats_fwd(_dev(inp, "in", torch.float32), B, inp.numel() // B, sums.shape[1], _dev(sums, "sums", torch.float32), _stream()),
            "ada_depth_stats_fwd")
+
+
+def token_diversity(tap, ld, batch, rows_per_image, dim, sums):
+    """tap: operand-typed [batch * rows_per_image, ld] -> sums fp32 [batch, ceil(dim / 64), 2] = per column chunk (sum Var_rows, sum E_rows[t^2]) (ada_token_diversity_fwd)."""
+    _check(load().ada_token_diversity_fwd(_dev(tap, "tap", operand_dtype()), ld, batch, rows_per_image, dim, _dev(sums, "sums", torch.float32), _stream()),
+           "ada_token_diversity_fwd")
 
 
 def normalize(inp, minmax_in, norm=None, obs=None):

@@ -36,6 +36,7 @@ from . import igemm as _igemm
 from . import layernorm as _layernorm
 from . import debug_epoch, instrumented, operand_dtype
 from . import depth_stats as k_depth_stats
+from . import token_diversity as k_token_diversity
 from . import patchify as k_patchify
 from . import pos_embed_resize as k_pos_embed_resize
 from . import rowstats_finalize as k_rowstats_finalize
@@ -444,7 +445,12 @@ class Workspace:
             hidden = pw_.blocks[0]["hidden"]
             self.hd = z(T, hidden)
         self.taps = [z(P, m * D) for _ in range(4)]
-        self.stat_sums = z(B, STAT_CHUNKS, 2, dtype=torch.float32)     # per-image (sum s, sum s (1 - s)) of the depth map, in chunks (ada_depth_stats_fwd)
+        # the precision ladder's per-image statistics, one buffer (one host read): stat_sums = (sum s, sum s (1 - s)) of the depth map in chunks
+        # (ada_depth_stats_fwd), stat_div = (sum of column variances, sum of column mean squares) of the last tap in 64-column chunks (ada_token_diversity_fwd)
+        G = (D + 63) // 64
+        self.stat_buf = z(B * (STAT_CHUNKS + G) * 2, dtype=torch.float32)
+        self.stat_sums = self.stat_buf[:B * STAT_CHUNKS * 2].view(B, STAT_CHUNKS, 2)
+        self.stat_div = self.stat_buf[B * STAT_CHUNKS * 2:].view(B, G, 2)
         if pw_.readout:
             self.cls_op = [z(B, m * D) for _ in range(4)]                          # final-LayerNorm'd class tokens, operand-typed
             self.cls_bias = [z(B, D, dtype=torch.float32) for _ in range(4)]       # W_cls cls + b per image
@@ -568,6 +574,7 @@ class DepthEngine:
         self._ws_hi: "OrderedDict[tuple, Workspace]" = OrderedDict()
         self.escalated = 0            # images the ladder has re-run so far
         self.last_ratio = None        # per-image sum s(1-s) / sum s of the most recent call (CPU tensor), None when the ladder is off
+        self.last_diversity = None    # per-image token diversity of the last tap (see _escalate)
         self._ws: "OrderedDict[tuple, Workspace]" = OrderedDict()
         self._graphs: "OrderedDict[tuple, object]" = OrderedDict()   # key -> _GraphedForward | False (capture refused) | int (sightings)
         self._lock = threading.Lock()
@@ -680,8 +687,12 @@ class DepthEngine:
         single-precision head exceeds the 1e-3 bar (reference fixtures vitl_518_m10, vitb_518_zeros, ...).  r is computed from the output itself
         (ada_depth_stats_fwd, one deterministic reduction); for the images whose r exceeds the threshold the HEAD ONLY (27 % of the FLOPs) is re-run
         in split precision from the four taps, which this engine keeps [hi | lo] for the purpose, and its result replaces theirs.  The decision is a
-        pure function of the image's own first-rung output: deterministic, independent of the rest of the batch.  Costs one host read of 16 floats
-        per image (the forward's only synchronisation); off under stream capture (a caller's own HIP graph cannot hold a data-dependent branch)."""
+        pure function of the image's own first-rung results: deterministic, independent of the rest of the batch.  Second trigger: the TOKEN DIVERSITY
+        of the last tap (ada_token_diversity_fwd: sum of the feature columns' variances over the image's patch tokens / sum of their mean squares) --
+        0.23-0.53 on noise and image-like inputs, 0.02 on constant and checkerboard images, where every patch token is the same up to its position
+        and the head's rounding errors add coherently over positions (ViT-B, all-zero input at output mean 0.50: 1.29e-3 on the first rung, 3.6e-4 on
+        the second; profiles/r05_h_*).  Costs one host read of ~50 floats per image (the forward's only synchronisation); off under stream capture
+        (a caller's own HIP graph cannot hold a data-dependent branch)."""
         lad = self.ladder
         if lad is None:
             return out
@@ -690,11 +701,16 @@ class DepthEngine:
         B, H, W = out.shape[0], out.shape[-2], out.shape[-1]
         if ws is None:
             ws = self.workspace(B, H, W, out.device)
+        D = self.w.dim
         k_depth_stats(out, ws.stat_sums)
-        st = ws.stat_sums.cpu().double().sum(1)
+        k_token_diversity(ws.taps[3], ws.taps[3].shape[1], B, ws.ph * ws.pw, D, ws.stat_div)
+        host = ws.stat_buf.cpu().double()                       # the forward's one synchronisation: (8 + D / 64) x 2 floats per image
+        nst = B * STAT_CHUNKS * 2
+        st, dv = host[:nst].view(B, STAT_CHUNKS, 2).sum(1), host[nst:].view(B, -1, 2).sum(1)
         ratio = st[:, 1] / st[:, 0].clamp_min(1e-300)
-        self.last_ratio = ratio
-        idx = torch.nonzero(ratio > lad["r"]).flatten()
+        diversity = dv[:, 0] / dv[:, 1].clamp_min(1e-300)
+        self.last_ratio, self.last_diversity = ratio, diversity
+        idx = torch.nonzero((ratio > lad["r"]) | (diversity < lad.get("div", 0.0))).flatten()
         if idx.numel() == 0:
             return out
         if self._w_hi is None:

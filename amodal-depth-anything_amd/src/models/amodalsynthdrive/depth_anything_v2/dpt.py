@@ -188,11 +188,14 @@ def _encoder_split_policy(mode, encoder, final_act):
 # LOGIT error of ~1.2e-3 (ViT-L) that the sigmoid compresses by r = sum s (1 - s) / sum s in the north-star metric mean|a - b| / mean|b|: r is 0.3-0.5
 # for depth maps that span (0, 1) -- every centred reference fixture, the benchmarked batch -- and tends to 1 for maps concentrated near 0, where the
 # default policy measured 1.17e-3 (ViT-L, mean 0.10) ... 2.3e-3 (ViT-B, all-zero image): profiles/r04_s_sigmoid_operating_point.txt.  Images whose
-# first-rung output has r above the threshold get their HEAD re-run in split precision from the (always [hi | lo]) taps.  Threshold per encoder,
-# chosen on the reference fixtures of round 5 (profiles/r05_a_precision_ladder.txt: first-rung rel-L1 ~ 1.8e-3 r on ViT-B, ~ 1.65e-3 r on ViT-L over
-# centred, low-mean, constant and checkerboard inputs alike, so the rung holds 8.5e-4 up to r = 0.47 / 0.50; the benchmarked batch has r <= 0.43, the
-# centred fixtures r <= 0.46); ADA_LADDER_R overrides ("0" / "off" disables the ladder).
-_LADDER_R = {"vitb": 0.47, "vitl": 0.50}
+# first-rung output has r above the threshold get their HEAD re-run in split precision from the (always [hi | lo]) taps.  Threshold per encoder from the
+# reference fixtures of round 5 (profiles/r05_h_precision_ladder.txt): first-rung rel-L1 / r is a property of the model -- ViT-B 1.6e-3 ... 2.3e-3 (image-like
+# inputs at the top), ViT-L 1.5e-3 ... 2.1e-3 (heavy-tailed weights at the top) -- over centred, low-mean and structured inputs alike, so the rung
+# holds ~9e-4 up to r = 0.42 / 0.45; the benchmarked batch has r <= 0.43, the centred noise fixtures r <= 0.41.  Second trigger: token diversity of the last
+# tap below _LADDER_DIV (constant / checkerboard inputs: 0.02; everything else >= 0.23), where rounding errors add coherently over positions.
+# ADA_LADDER_R overrides the threshold ("0" / "off" disables the ladder).
+_LADDER_R = {"vitb": 0.42, "vitl": 0.45}
+_LADDER_DIV = 0.10
 
 
 def _ladder_threshold(module, encoder, final_act, mode):
@@ -270,7 +273,7 @@ class _EngineMixin:
             ladder = None
             if ladder_r is not None:
                 encoder = self.encoder
-                ladder = dict(r=ladder_r, make=lambda: PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=HEAD_GROUPS, head_only=True))
+                ladder = dict(r=ladder_r, div=_LADDER_DIV, make=lambda: PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=HEAD_GROUPS, head_only=True))
             object.__setattr__(self, "_engine_obj", DepthEngine(pw, self.depth_head.final_act, bool(getattr(self, "normalise_input", False)), ladder=ladder))
             object.__setattr__(self, "_engine_stamp", stamp)
         return self._engine_obj

@@ -360,6 +360,11 @@ int ada_blend_fwd(const float* amodal, const float* base, const float* mask, int
  * is the factor by which the sigmoid compresses the head's logit error in mean|a - b| / mean|b| for this image: hip_ext/engine.py's precision
  * ladder re-runs the DPT head in split precision for the images where it is large (depth maps concentrated near 0).  No reference counterpart. */
 int ada_depth_stats_fwd(const float* in, int32_t batch, int64_t n_per_image, int32_t chunks, float* sums, void* stream);
+/* Token diversity of an encoder tap (operand-typed [batch * rows_per_image, ld], the first `dim` columns of a row): for image b and column chunk j
+ * (64 columns; ceil(dim / 64) chunks)  sums[(b * chunks + j) * 2 + {0, 1}] = (sum over the chunk's columns of Var_rows, sum of E_rows[t^2]).  The caller adds the
+ * chunks; sum Var / sum E[t^2] ~ 0.02 marks inputs whose patch tokens are all alike (constant images), where the head's operand rounding errors add
+ * coherently: the second trigger of hip_ext/engine.py's precision ladder.  No reference counterpart. */
+int ada_token_diversity_fwd(const void* tap, int64_t ld, int32_t batch, int32_t rows_per_image, int32_t dim, float* sums, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Tiled inference for inputs larger than the network's native 518 x 518 (the reference squashes every

@@ -290,6 +290,40 @@ def test_tapsum_resize_right_edge_halo_column_reads_staged_data(hip, wo):
         assert err < 3e-3, f"wo={wo} {tdt}: last two columns rel-L1 {err:.2e}"
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 518, 518), (1, 14, 14), (2, 126, 154)])
+def test_depth_stats_per_image_moments(hip, B, H, W):
+    """ada_depth_stats_fwd: per-image (sum s, sum s (1 - s)) in fixed-order chunks -- the precision ladder's first trigger."""
+    s_ = torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(5)).to(DEV)
+    sums = torch.full((B, 8, 2), float("nan"), device=DEV)
+    hip.depth_stats(s_, sums)
+    got = sums.cpu().double().sum(1)
+    ref = torch.stack([s_.cpu().double().flatten(1).sum(1), (s_.cpu().double() * (1 - s_.cpu().double())).flatten(1).sum(1)], dim=1)
+    assert torch.allclose(got, ref, rtol=2e-6), (got, ref)
+    again = torch.empty_like(sums)
+    hip.depth_stats(s_, again)
+    assert torch.equal(sums, again)       # no atomics: bit-reproducible
+
+
+@pytest.mark.parametrize("B,Np,D,ld", [(2, 1369, 768, 768), (3, 99, 1024, 2048), (1, 1, 384, 384), (2, 37, 100, 128)])
+def test_token_diversity_of_a_tap(hip, B, Np, D, ld):
+    """ada_token_diversity_fwd: sum of the columns' variances over an image's tokens and sum of their mean squares, per 64-column chunk -- ~0 for an image
+    whose tokens are all alike (the ladder's second trigger), the [hi | lo] lo half of a split tap ignored (ld > dim)."""
+    op = _op(hip)
+    t = _rand(B, Np, ld, seed=81).to(op)
+    if B > 1:
+        t[1, :, :D] = t[1, :1, :D].clone()       # image 1: every token equal
+    t = t.reshape(B * Np, ld).contiguous().to(DEV)
+    G = (D + 63) // 64
+    sums = torch.full((B, G, 2), float("nan"), device=DEV)
+    hip.token_diversity(t, ld, B, Np, D, sums)
+    got = sums.cpu().double().sum(1)
+    x = t.cpu().double().view(B, Np, ld)[:, :, :D]
+    ref = torch.stack([x.var(dim=1, unbiased=False).sum(-1), (x * x).mean(dim=1).sum(-1)], dim=1)
+    assert torch.allclose(got, ref, rtol=1e-3, atol=1e-3 * float(ref[:, 1].max())), (got, ref)
+    if B > 1 and Np > 1:
+        assert float(got[1, 0] / got[1, 1]) < 1e-3 < float(got[0, 0] / got[0, 1])
+
+
 @pytest.mark.parametrize("M,N,K", [(9 * 256, 16 * 256, 256), (9 * 96, 4 * 96, 96), (1152, 256, 256), (7, 5, 3)])
 def test_compose_f32_weight_products(hip, M, N, K):
     """functional.compose_f32 (weight composition at pack time: sub-pixel merges, output_conv1 o out_conv) on the library's own split-precision GEMM

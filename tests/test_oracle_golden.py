@@ -16,7 +16,7 @@ SLOW_ONLY = ("raw_vitg_1022", "vitl_714x1022", "vitl_1022", "vitl_ssi_1022", "vi
              # further draws of ViT-L families that have a replayed fixture already (vitl_ssi_518, raw_vitl_518, vitl_518): 15-20 s of CPU each
              "vitl_ssi_518_w1", "vitl_ssi_518_w2", "vitl_ssi_518_heavy", "vitl_518_heavy", "raw_vitl_518_heavy", "raw_vitl_518_heavy_w1",
              # round 5, off-centre sigmoid fixtures: vitl_518_m10 is replayed, its siblings only with ADA_SLOW_TESTS
-             "vitl_518_struct_m20", "vitl_518_zeros", "bench_vitl_b32_low")
+             "vitl_518_struct_m20", "vitl_518_zeros", "vitl_518_zeros_c", "bench_vitl_b32_low")
 ORDER = sorted(golden_names(), key=lambda n: ("vitl" in n or "vitg" in n, n))
 
 

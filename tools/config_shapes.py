@@ -19,6 +19,7 @@ from src.util.synth_weights import centred_final_bias, fill_state_dict_, make_in
 
 E.GRAPH_MODE = "0"
 ENC, B, SWEEP, REPS = os.environ.get("ENCODER", "vitb"), int(os.environ.get("B", "8")), os.environ.get("SWEEP") == "1", int(os.environ.get("REPS", "10"))
+RAW, SIZE = os.environ.get("RAW") == "1", int(os.environ.get("SIZE", "518"))     # RAW=1 SIZE=1022 ENCODER=vitg B=8: BASELINE config 5
 TILE = {0: (256, 32, 2), 1: (128, 64, 3), 2: (256, 128, 1), 3: (256, 256, 1), 4: (128, 128, 2)}   # code -> (BM, BN, workgroups per CU)
 NAMES = ("igemm", "attention", "layernorm", "patchify", "write_cls", "bilinear", "dpt_tail", "tapsum_resize")
 
@@ -37,16 +38,25 @@ def timeit(fn, reps=REPS):
 
 
 def main():
-    m = get_model("AmodalDAv2", guide_type="mask+observation", loss_stategy="entire_target_object", encoder=ENC, pretrained=False).eval()
-    sd = {k: v.clone() for k, v in m.state_dict().items()}
-    fill_state_dict_(sd, 0)
-    cb = centred_final_bias(ENC, ROOT)      # centred logits: the default (first-rung) path is what is timed
-    if cb:
-        sd[cb[0]] = torch.full_like(sd[cb[0]], cb[1])
-    m.load_state_dict(sd)
-    m = m.cuda()
-    x, _, mask, obs = make_inputs(B, 518, 518, 0, device="cuda")
-    run = lambda: m(x, guide_mask=mask, observation=obs)     # noqa: E731
+    if RAW:
+        from src.models.amodalsynthdrive.depth_anything_v2_raw.dpt import DepthAnythingV2 as Raw
+        feats = {"vits": (64, [48, 96, 192, 384]), "vitb": (128, [96, 192, 384, 768]), "vitl": (256, [256, 512, 1024, 1024]), "vitg": (384, [1536] * 4)}[ENC]
+        m = Raw(encoder=ENC, features=feats[0], out_channels=feats[1]).eval()
+        fill_state_dict_(m.state_dict(), 0)
+        m = m.cuda()
+        x = torch.randn(B, 3, SIZE, SIZE, device="cuda")
+        run = lambda: m(x)     # noqa: E731
+    else:
+        m = get_model("AmodalDAv2", guide_type="mask+observation", loss_stategy="entire_target_object", encoder=ENC, pretrained=False).eval()
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        fill_state_dict_(sd, 0)
+        cb = centred_final_bias(ENC, ROOT)      # centred logits: the default (first-rung) path is what is timed
+        if cb:
+            sd[cb[0]] = torch.full_like(sd[cb[0]], cb[1])
+        m.load_state_dict(sd)
+        m = m.cuda()
+        x, _, mask, obs = make_inputs(B, SIZE, SIZE, 0, device="cuda")
+        run = lambda: m(x, guide_mask=mask, observation=obs)     # noqa: E731
     with torch.no_grad():
         run()
         whole = timeit(run, 5)
@@ -71,8 +81,9 @@ def main():
         else:
             key = (name,)
         groups.setdefault(key, []).append((a, k))
-    print(f"# precision ladder re-ran {m.encoder._engine().escalated} images during the warm-up / timing calls")
-    print(f"# AmodalDAv2 {ENC}, {B} x 518 x 518: whole forward {whole:.0f} us = {B / whole * 1e6:.1f} images/s; {len(calls)} launches, {len(groups)} distinct; launches timed alone ({REPS} reps, warm caches)")
+    eng = (m if RAW else m.encoder)._engine()
+    print(f"# precision ladder re-ran {eng.escalated} images during the warm-up / timing calls")
+    print(f"# {'raw DepthAnythingV2' if RAW else 'AmodalDAv2'} {ENC}, {B} x {SIZE} x {SIZE}: whole forward {whole:.0f} us = {B / whole * 1e6:.1f} images/s; {len(calls)} launches, {len(groups)} distinct; launches timed alone ({REPS} reps, warm caches)")
     rows = []
     for key, lst in groups.items():
         name = key[0]

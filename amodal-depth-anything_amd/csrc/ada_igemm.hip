@@ -1227,7 +1227,10 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force) {
         // relative main-loop efficiencies re-fitted after the move to 16x16x32 MFMAs (tools/autotune_shapes.py at B = 1 and 4:
         // the 128x64 tile with three co-resident workgroups wins more of the small problems than it used to)
         const long Kt = d.K;     // k-loop length (all taps / split segments)
-        double t2 = tile_time(d.M, d.N, 256, 128, 1, 0.72), t4 = tile_time(d.M, d.N, 128, 128, 2, 0.85), t1 = tile_time(d.M, d.N, 128, 64, 3, 0.80);
+        // (very long k-loops -- the 41472-deep split-precision 3x3 convs of the raw ViT-G head: the small tiles' efficiency is down to ~0.45 of the 256x256
+        //  tile's, profiles/r05_j_config5_shapes.txt: 128x64 3220 us against 2133 us there -- in the slot-rounded estimate too)
+        const double e4 = Kt >= 16384 ? 0.45 : 0.85, e1 = Kt >= 16384 ? 0.45 : 0.80;
+        double t2 = tile_time(d.M, d.N, 256, 128, 1, 0.72), t4 = tile_time(d.M, d.N, 128, 128, 2, e4), t1 = tile_time(d.M, d.N, 128, 64, 3, e1);
         const double t4c = tile_time_cu(d.M, d.N, Kt, 128, 128, 0.95, 0.095, 0.90), t1c = tile_time_cu(d.M, d.N, Kt, 128, 64, 0.90, 0.10, 0.85);
         if (t4c < t4) t4 = t4c;     // either estimate may make the case for the small tile
         if (t1c < t1) t1 = t1c;

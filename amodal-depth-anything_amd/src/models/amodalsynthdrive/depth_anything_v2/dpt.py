@@ -196,6 +196,10 @@ def _encoder_split_policy(mode, encoder, final_act):
 # ADA_LADDER_R overrides the threshold ("0" / "off" disables the ladder).
 _LADDER_R = {"vitb": 0.42, "vitl": 0.45}
 _LADDER_DIV = 0.10
+# What the second rung re-runs in split precision: the whole head -- on ViT-L without the ResidualConvUnit convolutions of the two finest levels (the four
+# 148^2 and four 74^2 convs: 23 % of the rung's MACs): on the five low-mean / constant ViT-L fixtures that subset is as good or better (5.8-6.5e-4 against
+# 5.4-7.5e-4 with everything split, profiles/r05_h_ladder_second_rung_subsets.txt); ViT-B needs them (8.5e-4 against 9.9e-4 on its worst fixture).
+_LADDER_SKIP = {"vitl": ("rcu0", "rcu1")}
 
 
 def _ladder_threshold(module, encoder, final_act, mode):
@@ -273,7 +277,8 @@ class _EngineMixin:
             ladder = None
             if ladder_r is not None:
                 encoder = self.encoder
-                ladder = dict(r=ladder_r, div=_LADDER_DIV, make=lambda: PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=HEAD_GROUPS, head_only=True))
+                groups = tuple(g for g in HEAD_GROUPS if g not in _LADDER_SKIP.get(encoder, ()) and g != "projw")
+                ladder = dict(r=ladder_r, div=_LADDER_DIV, make=lambda: PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=groups, head_only=True))
             object.__setattr__(self, "_engine_obj", DepthEngine(pw, self.depth_head.final_act, bool(getattr(self, "normalise_input", False)), ladder=ladder))
             object.__setattr__(self, "_engine_stamp", stamp)
         return self._engine_obj

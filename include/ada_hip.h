@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADA_ABI_VERSION 5
+#define ADA_ABI_VERSION 6   /* 6 (round 5): + ada_depth_stats_fwd, ada_token_diversity_fwd (additions only; every ABI-5 entry point and struct layout unchanged) */
 
 /* status codes */
 #define ADA_OK 0

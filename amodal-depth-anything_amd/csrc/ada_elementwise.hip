@@ -9,7 +9,7 @@
 
 namespace {
 
-// operand-typed float4 store; split_seg > 0 writes [hi | lo] column segments (split precision, see ada_igemm_args.split_seg)
+// operand-typed float4 store; split_seg > 0 writes [hi | lo] column segments (split precision, see ada_igemm_args.split_seg), < 0 the fp8 form
 ADA_DEV void store_op4_split(op_t* row, int c, float4 r, int split_seg) {
     opx4 o;
     o[0] = to_op(r.x); o[1] = to_op(r.y); o[2] = to_op(r.z); o[3] = to_op(r.w);
@@ -18,6 +18,10 @@ ADA_DEV void store_op4_split(op_t* row, int c, float4 r, int split_seg) {
         opx4 l;
         l[0] = to_op(r.x - (float)o[0]); l[1] = to_op(r.y - (float)o[1]); l[2] = to_op(r.z - (float)o[2]); l[3] = to_op(r.w - (float)o[3]);
         ((opx4*)(row + split_seg))[c] = l;
+    } else if (split_seg < 0) {   // [hi | lo8 | hi8]: e5m2 bytes behind the hi segment (ada_igemm_args.f8_from)
+        uint32_t* b = (uint32_t*)(row - split_seg);
+        b[c] = bf8x4((r.x - (float)o[0]) * ADA_F8_LO_SHIFT, (r.y - (float)o[1]) * ADA_F8_LO_SHIFT, (r.z - (float)o[2]) * ADA_F8_LO_SHIFT, (r.w - (float)o[3]) * ADA_F8_LO_SHIFT);
+        b[c + (-split_seg) / 4] = bf8x4(r.x, r.y, r.z, r.w);
     }
 }
 
@@ -31,6 +35,10 @@ ADA_DEV void store_op4_bil(op_t* row, int c, float4 r, int split_seg) {
         opx4 l;
         l[0] = to_op(r.x - (float)o[0]); l[1] = to_op(r.y - (float)o[1]); l[2] = to_op(r.z - (float)o[2]); l[3] = to_op(r.w - (float)o[3]);
         __builtin_nontemporal_store(l, ((opx4*)(row + split_seg)) + c);
+    } else if (split_seg < 0) {
+        uint32_t* b = (uint32_t*)(row - split_seg);
+        b[c] = bf8x4((r.x - (float)o[0]) * ADA_F8_LO_SHIFT, (r.y - (float)o[1]) * ADA_F8_LO_SHIFT, (r.z - (float)o[2]) * ADA_F8_LO_SHIFT, (r.w - (float)o[3]) * ADA_F8_LO_SHIFT);
+        b[c + (-split_seg) / 4] = bf8x4(r.x, r.y, r.z, r.w);
     }
 }
 ADA_DEV void store_f32_bil(float* ptr, float4 r) {
@@ -668,7 +676,8 @@ extern "C" int ada_layernorm_ex(const ada_layernorm_args* a, void* stream) {
     p.dMapW = make_fastdiv(a->map_w > 0 ? a->map_w : 1);
     p.dMapHW = make_fastdiv(a->map_h > 0 && a->map_w > 0 ? a->map_h * a->map_w : 1);
     p.relu = a->relu; p.out_f32 = a->out_f32; p.ld_f32 = a->ld_f32;
-    ADA_REQUIRE(a->split_seg == 0 || (a->out_op && a->split_seg >= dim && a->split_seg % 4 == 0 && a->ld_op >= 2L * a->split_seg), ADA_EINVAL, "ada_layernorm_fwd: bad split_seg=%d for dim=%d ld_op=%ld", a->split_seg, dim, (long)a->ld_op);
+    const int seg_abs = a->split_seg < 0 ? -a->split_seg : a->split_seg, seg2_abs = a->split_seg2 < 0 ? -a->split_seg2 : a->split_seg2;   // < 0: the [hi | lo8 | hi8] form
+    ADA_REQUIRE(a->split_seg == 0 || (a->out_op && seg_abs >= dim && seg_abs % 4 == 0 && a->ld_op >= 2L * seg_abs), ADA_EINVAL, "ada_layernorm_fwd: bad split_seg=%d for dim=%d ld_op=%ld", a->split_seg, dim, (long)a->ld_op);
     p.split_seg = a->split_seg;
     p.weight2 = a->weight2; p.bias2 = a->bias2; p.out2 = (op_t*)a->out2_op; p.ld2 = a->ld2_op;
     p.out2_group = a->out2_group > 0 ? a->out2_group : 1; p.out2_skip = a->out2_group > 0 ? a->out2_skip : 0; p.split_seg2 = a->split_seg2;
@@ -676,7 +685,7 @@ extern "C" int ada_layernorm_ex(const ada_layernorm_args* a, void* stream) {
     if (a->out2_op) {
         ADA_REQUIRE(a->weight2 && a->bias2 && a->ld2_op % 4 == 0 && a->group_in == 0 && a->unshuffle_s == 0, ADA_EINVAL, "ada_layernorm: the second output needs its own gain / bias, ld2 %% 4 == 0 and plainly ordered input rows");
         ADA_REQUIRE(a->out2_group == 0 || (a->out2_skip >= 0 && a->out2_skip < a->out2_group && rows_out % a->out2_group == 0), ADA_EINVAL, "ada_layernorm: bad out2 group/skip");
-        ADA_REQUIRE(a->split_seg2 == 0 || (a->split_seg2 >= dim && a->split_seg2 % 4 == 0 && a->ld2_op >= 2L * a->split_seg2), ADA_EINVAL, "ada_layernorm: bad split_seg2");
+        ADA_REQUIRE(a->split_seg2 == 0 || (seg2_abs >= dim && seg2_abs % 4 == 0 && a->ld2_op >= 2L * seg2_abs), ADA_EINVAL, "ada_layernorm: bad split_seg2");
     }
     p.identity = a->identity;
     p.unshuffle_s = a->unshuffle_s; p.dUnS = make_fastdiv(a->unshuffle_s > 0 ? a->unshuffle_s : 1); p.tap_bias = a->tap_bias;
@@ -804,7 +813,8 @@ extern "C" int ada_bilinear_fwd(const float* in, int64_t ld_in, int32_t batch, i
     p.sx = wo > 1 ? (float)(wi - 1) / (float)(wo - 1) : 0.0f;
     p.add = add; p.ld_add = ld_add; p.out_f32 = out_f32; p.ld_f32 = ld_f32; p.out_op = (op_t*)out_op; p.ld_op = ld_op;
     p.map_op = map_op; p.relu = relu;
-    ADA_REQUIRE(split_seg == 0 || (out_op && split_seg >= channels && split_seg % 4 == 0 && ld_op >= 2L * split_seg), ADA_EINVAL, "ada_bilinear_fwd: bad split_seg=%d for %d channels, ld_op=%ld", split_seg, channels, (long)ld_op);
+    const int seg_abs = split_seg < 0 ? -split_seg : split_seg;   // < 0: the [hi | lo8 | hi8] form
+    ADA_REQUIRE(split_seg == 0 || (out_op && seg_abs >= channels && seg_abs % 4 == 0 && ld_op >= 2L * seg_abs), ADA_EINVAL, "ada_bilinear_fwd: bad split_seg=%d for %d channels, ld_op=%ld", split_seg, channels, (long)ld_op);
     p.split_seg = split_seg;
     p.dC4 = make_fastdiv(p.c4); p.dWo = make_fastdiv(wo); p.dHo = make_fastdiv(ho);
     ADA_REQUIRE(ho <= 65535 && batch <= 65535, ADA_EUNSUPPORTED, "ada_bilinear_fwd: ho / batch exceed the grid limits");

@@ -99,6 +99,9 @@ struct IgemmDev {
     int rowstat_groups;       // N / 64
     int split_seg;   // > 0: the op-typed output is written as [hi | lo] in two column segments of this width (split precision)
     int a_dup_seg;   // > 0: the A operand is a [hi | lo] split tensor contracted as (hi, lo, hi) against [w_hi | w_hi | w_lo] weights
+    int split_f8;    // the split output is [hi | lo8 | hi8] (bytes behind the hi segment) instead of [hi | lo]
+    int f8_from, f8_mid;   // k-steps (inside a period of the k-walk: all of K, or one conv tap) from which the operands are fp8 bytes / the scale pair changes; 0 = off
+    unsigned f8_scales;    // E8M0 scale bytes: A, W of [f8_from, f8_mid) in bits 0-15, A, W of [f8_mid, period) in bits 16-31
     // LayerNorm tail: after the tiles of a row panel have written the fp32 output, the LAST of them to arrive normalises the panel's rows
     const float* ln_weight;
     const float* ln_bias;
@@ -207,16 +210,25 @@ ADA_DEV opx4 pack4(float4 v) {
 // n + seg: a following contraction over the THREE k segments (hi, lo, hi) -- the third re-reads the first, ada_igemm_args.a_dup_seg --
 // against weights packed [w_hi | w_hi | w_lo] evaluates x_hi w_hi + x_lo w_hi + x_hi w_lo, i.e. the product to ~fp32 accuracy on the fp16
 // matrix cores (used for selected contractions of the DPT head and the patch embedding).
-ADA_DEV void store_op4(const IgemmDev& p, op_t* dst, float4 v) {
+// (col = dst's column inside its row: the byte segments of the [hi | lo8 | hi8] form start at row + seg, one byte per column)
+template <bool F8OK = true>
+ADA_DEV void store_op4(const IgemmDev& p, op_t* dst, int col, float4 v) {
     const opx4 h = pack4(v);
     *(opx4*)dst = h;
     if (p.split_seg > 0) {
         float4 r;
         r.x = v.x - (float)h[0]; r.y = v.y - (float)h[1]; r.z = v.z - (float)h[2]; r.w = v.w - (float)h[3];
-        *(opx4*)(dst + p.split_seg) = pack4(r);
+        if (F8OK && p.split_f8) {
+            char* b = (char*)dst + (2 * p.split_seg - col);        // = (char*)(row + seg) + col
+            *(uint32_t*)b = bf8x4(r.x * ADA_F8_LO_SHIFT, r.y * ADA_F8_LO_SHIFT, r.z * ADA_F8_LO_SHIFT, r.w * ADA_F8_LO_SHIFT);
+            *(uint32_t*)(b + p.split_seg) = bf8x4(v.x, v.y, v.z, v.w);
+        } else {
+            *(opx4*)(dst + p.split_seg) = pack4(r);
+        }
     }
 }
-ADA_DEV void store_op8(const IgemmDev& p, op_t* dst, float4 v0, float4 v1) {
+template <bool F8OK = true>
+ADA_DEV void store_op8(const IgemmDev& p, op_t* dst, int col, float4 v0, float4 v1) {
     const opx4 lo = pack4(v0), hi4 = pack4(v1);
     opx8 o;
     o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
@@ -235,6 +247,17 @@ ADA_DEV void store_op8(const IgemmDev& p, op_t* dst, float4 v0, float4 v1) {
         float4 r0, r1;
         r0.x = v0.x - (float)lo[0]; r0.y = v0.y - (float)lo[1]; r0.z = v0.z - (float)lo[2]; r0.w = v0.w - (float)lo[3];
         r1.x = v1.x - (float)hi4[0]; r1.y = v1.y - (float)hi4[1]; r1.z = v1.z - (float)hi4[2]; r1.w = v1.w - (float)hi4[3];
+        if (F8OK && p.split_f8) {
+            char* b8 = (char*)dst + (2 * p.split_seg - col);       // = (char*)(row + seg) + col
+            u32x2 l8, h8;
+            l8[0] = bf8x4(r0.x * ADA_F8_LO_SHIFT, r0.y * ADA_F8_LO_SHIFT, r0.z * ADA_F8_LO_SHIFT, r0.w * ADA_F8_LO_SHIFT);
+            l8[1] = bf8x4(r1.x * ADA_F8_LO_SHIFT, r1.y * ADA_F8_LO_SHIFT, r1.z * ADA_F8_LO_SHIFT, r1.w * ADA_F8_LO_SHIFT);
+            h8[0] = bf8x4(v0.x, v0.y, v0.z, v0.w);
+            h8[1] = bf8x4(v1.x, v1.y, v1.z, v1.w);
+            *(u32x2*)b8 = l8;
+            *(u32x2*)(b8 + p.split_seg) = h8;
+            return;
+        }
         const opx4 a = pack4(r0), b = pack4(r1);
         opx8 l;
         l[0] = a[0]; l[1] = a[1]; l[2] = a[2]; l[3] = a[3];
@@ -514,7 +537,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
         // All copies of slab t+1 are issued right after the barrier; fragment reads are scheduled by the compiler.
         // (Hand-counted lgkmcnt pipelines and a ping-pong split of the two waves per SIMD were tried and measured: fewer
         // cycles per k-step but no wall-clock gain on this power-limited kernel -- profiles/r01_c_gemm_sched{4,5}_ab.txt.)
-        for (int kt = 0; kt < nk; ++kt) {
+        // One k-step; F8: the slab's 128-byte rows hold 128 e5m2 (A) / e4m3 (W) codes (ada_igemm_args.f8_from) and go to the fp8 instruction.  The two
+        // kinds of step live in two loops, not behind a branch in one: with both in one body the register allocator gives up tying the accumulators.
+        auto k_step = [&](int kt, Walk w, unsigned sc, auto f8_tag) __attribute__((always_inline)) -> Walk {
+            constexpr bool F8 = decltype(f8_tag)::value;
             const int cur = kt & 1;
             unsigned long long tw0 = 0, tw1 = 0;
             if (p.dbg) tw0 = __builtin_amdgcn_s_memtime();
@@ -535,7 +561,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             const bool late = (NWAVES == 8) && wave < 4;
             const bool more = kt + 1 < nk;
             long aoff = 0, boff = 0;
-            if (more) walk = next_offsets(walk, aoff, boff);
+            if (more) w = next_offsets(w, aoff, boff);
             // (Spreading the 8 copies of a wave over the MFMAs of "its" k half -- two behind every 8 MFMAs, order pinned with sched_barrier, the
             // thing that was worth 20 % in the 4-wave loop -- makes THIS loop slower: fc1 +10 %, fc2 +14 %, 8192^3 +20 %; the partner wave on the
             // SIMD already covers a burst, and the pins cost the compiler its own schedule.  profiles/r03_i_gemm_4wave_asm_loop.txt)
@@ -543,32 +569,82 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             const char* sbase = smem + cur * STAGE_BYTES;
             const int l15 = lane & 15, q4 = lane >> 4;
             const int a16_off = (wm * TI * 32 + l15) * RB, b16_off = A_BYTES + (wn * TJ * 32 + l15) * RB;
-#pragma unroll
-            for (int s = 0; s < BK / 32; ++s) {   // 32-wide k halves
-                const int coff = ((4 * s + q4) ^ (CHUNKS == 8 ? ((l15 >> 1) & 7) : ((l15 >> 2) & 3))) * 16;
-                opx8 af[TI][2], bf[TJ][2];
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) af[i][a] = *(const opx8*)(sbase + a16_off + (i * 32 + a * 16) * RB + coff);
+            if constexpr (F8) {
+                // a lane's two 16-byte chunks q4 and 4 + q4 -- the addresses of the fp16 step's two k halves -- are its 32 bytes of one 16x16x128 issue
+                // (A and W split k the same way, which is all the contraction needs)
+                const int sa = (int)(sc & 255u), sb = (int)((sc >> 8) & 255u);
+                const int key = (l15 >> 1) & 7;
+                const int c0 = ((q4 ^ key) * 16), c1 = (((4 + q4) ^ key) * 16);
+                auto frag8 = [&](int off) -> i32x8 {
+                    const u32x4 x = *(const u32x4*)(sbase + off + c0), y = *(const u32x4*)(sbase + off + c1);
+                    i32x8 r;
+                    r[0] = (int)x[0]; r[1] = (int)x[1]; r[2] = (int)x[2]; r[3] = (int)x[3];
+                    r[4] = (int)y[0]; r[5] = (int)y[1]; r[6] = (int)y[2]; r[7] = (int)y[3];
+                    return r;
+                };
+                i32x8 bf8[TJ][2];
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                    for (int b2 = 0; b2 < 2; ++b2) bf[j][b2] = *(const opx8*)(sbase + b16_off + (j * 32 + b2 * 16) * RB + coff);
+                    for (int b2 = 0; b2 < 2; ++b2) bf8[j][b2] = frag8(b16_off + (j * 32 + b2 * 16) * RB);
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
 #pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const i32x8 af8 = frag8(a16_off + (i * 32 + a * 16) * RB);
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                            for (int b2 = 0; b2 < 2; ++b2) acc[i][j][2 * a + b2] = mfma16_f8(af8, bf8[j][b2], acc[i][j][2 * a + b2], sa, sb);
+                    }
+                    // (the A fragments of one 32-row block at a time: hoisted together, the eight of the 256x256 tile do not fit beside its 128 accumulators)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i == (TI - 1) / 2) {
+                        if (more && late) stage_part(cur ^ 1, aoff, boff, -1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                f8_hazard_fence();
+            } else {
+#pragma unroll
+                for (int s = 0; s < BK / 32; ++s) {   // 32-wide k halves
+                    const int coff = ((4 * s + q4) ^ (CHUNKS == 8 ? ((l15 >> 1) & 7) : ((l15 >> 2) & 3))) * 16;
+                    opx8 af[TI][2], bf[TJ][2];
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) af[i][a] = *(const opx8*)(sbase + a16_off + (i * 32 + a * 16) * RB + coff);
+#pragma unroll
                     for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                        for (int a = 0; a < 2; ++a)
+                        for (int b2 = 0; b2 < 2; ++b2) bf[j][b2] = *(const opx8*)(sbase + b16_off + (j * 32 + b2 * 16) * RB + coff);
 #pragma unroll
-                            for (int b2 = 0; b2 < 2; ++b2) acc[i][j][2 * a + b2] = mfma16(af[i][a], bf[j][b2], acc[i][j][2 * a + b2]);
+                    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                                for (int b2 = 0; b2 < 2; ++b2) acc[i][j][2 * a + b2] = mfma16(af[i][a], bf[j][b2], acc[i][j][2 * a + b2]);
+                    }
+                    if (s == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more && late) stage_part(cur ^ 1, aoff, boff, -1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-                if (s == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more && late) stage_part(cur ^ 1, aoff, boff, -1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            }
+            return w;
+        };
+        if (BK != 64 || p.f8_from == 0) {
+            for (int kt = 0; kt < nk; ++kt) walk = k_step(kt, walk, 0u, std::false_type{});
+        } else {
+            // periods of the k-walk (all of K; one tap of a 3x3 conv): f8_from fp16 steps, then fp8 steps whose scale pair changes at f8_mid
+            const int per = p.a_mode == ADA_A_PLAIN ? nk : cps;
+            for (int kt = 0; kt < nk;) {
+                for (int r = 0; r < p.f8_from; ++r, ++kt) walk = k_step(kt, walk, 0u, std::false_type{});
+                for (int r = p.f8_from; r < p.f8_mid; ++r, ++kt) walk = k_step(kt, walk, p.f8_scales, std::true_type{});
+                for (int r = p.f8_mid; r < per; ++r, ++kt) walk = k_step(kt, walk, p.f8_scales >> 16, std::true_type{});
             }
         }
     }
@@ -745,10 +821,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                             v1.x = __builtin_fmaxf(v1.x, 0.f); v1.y = __builtin_fmaxf(v1.y, 0.f); v1.z = __builtin_fmaxf(v1.z, 0.f); v1.w = __builtin_fmaxf(v1.w, 0.f);
                         }
                         if (pad) {
-                            store_op8(p, p.out_op + walk.prow * ld + n, v0, v1);
+                            store_op8(p, p.out_op + walk.prow * ld + n, n, v0, v1);
                             pad_step(p, walk, RPI);
                         } else {
-                            store_op8(p, dst + (long)(i * 32 + k * RPI) * ld, v0, v1);
+                            store_op8(p, dst + (long)(i * 32 + k * RPI) * ld, n, v0, v1);
                         }
                     }
                 }
@@ -824,10 +900,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                             v.z = __builtin_fmaxf(v.z, 0.f); v.w = __builtin_fmaxf(v.w, 0.f);
                         }
                         if (pad) {
-                            store_op4(p, p.out_op + walk.prow * ldo + n, v);
+                            store_op4(p, p.out_op + walk.prow * ldo + n, n, v);
                             pad_step(p, walk, RPI);
                         } else {
-                            store_op4(p, p.out_op + (mrow + k * RPI) * ldo + n, v);
+                            store_op4(p, p.out_op + (mrow + k * RPI) * ldo + n, n, v);
                         }
                     }
                 }
@@ -918,8 +994,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                             orow = map_row(p, p.map_op, (uint32_t)m);
                         }
                         op_t* dst = p.out_op + orow * p.ldo_op + ocol;
-                        if (nval2) store_op8(p, dst, v0, v1);
-                        else store_op4(p, dst, v0);
+                        if (nval2) store_op8(p, dst, ocol, v0, v1);
+                        else store_op4<EPI != EPI_SHUFFLE>(p, dst, ocol, v0);   // (behind a shuffle the fp8 form needs shuffle_c % 8 == 0 -- validated -- so it never gets here:
+                                                                                 //  with its code in this branch too the 256x256 shuffle kernel spills two registers)
                     }
                 }
             }
@@ -1027,7 +1104,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                         } else {
                             orow = map_row(p, p.map_op, (uint32_t)m);
                         }
-                        store_op4(p, p.out_op + orow * p.ldo_op + ocol, v);
+                        store_op4<EPI != EPI_SHUFFLE>(p, p.out_op + orow * p.ldo_op + ocol, ocol, v);
                     }
                 }
             }
@@ -1208,7 +1285,7 @@ static inline double tile_time_cu(long M, long N, long K, int bm, int bn, double
 // main loop of the 256x256 tile: variant 16 forces the hand-scheduled 4-wave loop, 4 the single-barrier 8-wave loop; 0 (default) picks the
 // 4-wave loop where its main loop outweighs its slower prologue / epilogue (measured: k-loops of >= 128 k-tiles)
 // (its scalar A-offset counters assume a monotonic walk: a split operand, whose third k segment re-reads the first, stays on the 8-wave loop)
-static inline bool use_pipe4(const IgemmDev& d) { return d.a_dup_seg == 0 && d.a_wrap == 0 && d.tap_cols == 0 && d.ln_out == nullptr && (d.variant >= 16 || (d.variant == 0 && d.K >= 8192)); }
+static inline bool use_pipe4(const IgemmDev& d) { return d.a_dup_seg == 0 && d.a_wrap == 0 && d.f8_from == 0 && d.tap_cols == 0 && d.ln_out == nullptr && (d.variant >= 16 || (d.variant == 0 && d.K >= 8192)); }
 
 template <int EPI>
 int launch_epi(IgemmDev& d, hipStream_t s, int force) {
@@ -1361,10 +1438,12 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
                     "ada_igemm: EP_ROWSTATS is implemented for the fp32 / residual epilogue with a plain row map");
         ADA_REQUIRE(((uintptr_t)a->rowstat_out % 8) == 0, ADA_EINVAL, "ada_igemm: rowstat_out must be 8-byte aligned");
     }
+    const int split_abs = a->split_seg < 0 ? -a->split_seg : a->split_seg;   // < 0: the [hi | lo8 | hi8] form
     if (a->split_seg != 0) {
-        ADA_REQUIRE(a->out_op && a->split_seg > 0 && a->split_seg % 8 == 0 && !swiglu, ADA_EINVAL, "ada_igemm: split_seg needs out_op, a positive multiple of 8, no SwiGLU");
+        ADA_REQUIRE(a->out_op && split_abs % 8 == 0 && !swiglu, ADA_EINVAL, "ada_igemm: split_seg needs out_op, a multiple of 8, no SwiGLU");
+        ADA_REQUIRE(a->split_seg > 0 || !shuffle || a->shuffle_c % 8 == 0, ADA_EUNSUPPORTED, "ada_igemm: the fp8 form of a split output (split_seg < 0) behind MAP_SHUFFLE needs shuffle_c %% 8 == 0");
         const int cols = shuffle ? a->shuffle_c : a->N;
-        ADA_REQUIRE(cols <= a->split_seg && a->ldo_op >= 2L * a->split_seg, ADA_EINVAL, "ada_igemm: split_seg=%d too small for %d columns / ldo_op=%ld", a->split_seg, cols, (long)a->ldo_op);
+        ADA_REQUIRE(cols <= split_abs && a->ldo_op >= 2L * split_abs, ADA_EINVAL, "ada_igemm: split_seg=%d too small for %d columns / ldo_op=%ld", a->split_seg, cols, (long)a->ldo_op);
     }
     if (a->ln_out) {
         ADA_REQUIRE(a->ln_weight && a->ln_bias && a->ln_counter && a->out_f32 && a->map_f32 == ADA_MAP_PLAIN && a->res_row_mod == 0 && !tail && !swiglu && !shuffle &&
@@ -1381,6 +1460,12 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     if (a->a_wrap != 0) {
         ADA_REQUIRE(a->a_mode == ADA_A_PLAIN && a->a_dup_seg == 0 && a->a_wrap > 0 && a->a_wrap % 64 == 0 && a->K == 2 * a->a_wrap && a->lda >= a->a_wrap, ADA_EINVAL,
                     "ada_igemm: a_wrap=%d needs a plain operand, K == 2 * a_wrap (K=%d) and lda >= a_wrap", a->a_wrap, a->K);
+    }
+    if (a->f8_from != 0) {
+        const long per = a->a_mode == ADA_A_CONV3 ? a->lda : (long)a->K;     // period of the k-walk in operand slots
+        ADA_REQUIRE(a->a_dup_seg == 0 && a->a_wrap == 0 && !(f & ADA_EP_LNFOLD), ADA_EINVAL, "ada_igemm: f8_from excludes a_dup_seg / a_wrap / EP_LNFOLD");
+        ADA_REQUIRE(a->f8_from > 0 && a->f8_from % 64 == 0 && a->f8_mid % 64 == 0 && a->f8_from <= a->f8_mid && a->f8_mid <= per && a->f8_from < per, ADA_EINVAL,
+                    "ada_igemm: f8_from=%d / f8_mid=%d must be multiples of 64 with 0 < f8_from <= f8_mid <= %ld (the period of the k-walk)", a->f8_from, a->f8_mid, per);
     }
     if (a->tap_cols != 0) {
         ADA_REQUIRE(a->a_mode == ADA_A_CONV3 && a->tap_cols > 0 && a->N % a->tap_cols == 0 && a->N / a->tap_cols <= 16, ADA_EINVAL,
@@ -1411,7 +1496,9 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.dMapW = make_fastdiv(a->map_w > 0 ? a->map_w : 1);
     d.dMapHW = make_fastdiv(token ? a->map_h : (a->map_h > 0 && a->map_w > 0 ? a->map_h * a->map_w : 1));
     d.shuffle_s = a->shuffle_s; d.shuffle_c = a->shuffle_c;
-    d.split_seg = a->split_seg;
+    d.split_seg = split_abs;
+    d.split_f8 = a->split_seg < 0;
+    d.f8_from = a->f8_from / 64; d.f8_mid = a->f8_mid / 64; d.f8_scales = a->f8_scales;
     d.a_dup_seg = a->a_dup_seg;
     d.a_wrap = a->a_wrap;
     d.ln_weight = a->ln_weight; d.ln_bias = a->ln_bias; d.ln_eps = a->ln_eps; d.ln_out = (op_t*)a->ln_out; d.ld_ln = a->ld_ln;

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
 # --- constants mirrored from include/ada_hip.h ------------------------------------------------
-ABI_VERSION = 6
+ABI_VERSION = 7
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 A_PLAIN, A_CONV3 = 0, 1
 MAP_PLAIN, MAP_PAD, MAP_TOKEN, MAP_SHUFFLE = 0, 1, 2, 3
@@ -55,6 +55,7 @@ class IgemmArgs(ctypes.Structure):
         ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("rowstat_out", c_void_p), ("split_seg", c_int32), ("a_dup_seg", c_int32),
         ("tap_cols", c_int32), ("tap_mask", c_uint16 * 16), ("a_wrap", c_int32), ("bias_row_mod", c_int32),
         ("ln_weight", c_void_p), ("ln_bias", c_void_p), ("ln_eps", c_float), ("ln_out", c_void_p), ("ld_ln", c_int64), ("ln_counter", c_void_p),
+        ("f8_from", c_int32), ("f8_mid", c_int32), ("f8_scales", ctypes.c_uint32),
     ]
 
 
@@ -228,7 +229,8 @@ def set_timer(t: Optional[KernelTimer]):
 def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=None, gamma=None, res=None, ldr=0,
           res_row_mod=0, res_row_off=0, flags=0, out_f32=None, ldo_f32=0, map_f32=MAP_PLAIN, out_op=None, ldo_op=0,
           map_op=MAP_PLAIN, map_h=0, map_w=0, shuffle_s=0, shuffle_c=0, tail_w=None, tail_b=0.0, tail_act=ACT_NONE, split_seg=0,
-          ln_stats=None, ln_colsum=None, rowstat_out=None, a_dup_seg=0, tap_cols=0, tap_mask=None, a_wrap=0, bias_row_mod=0, ln_weight=None, ln_bias=None, ln_eps=0.0, ln_out=None, ld_ln=0, ln_counter=None):
+          ln_stats=None, ln_colsum=None, rowstat_out=None, a_dup_seg=0, tap_cols=0, tap_mask=None, a_wrap=0, bias_row_mod=0, ln_weight=None, ln_bias=None, ln_eps=0.0, ln_out=None, ld_ln=0, ln_counter=None,
+          f8_from=0, f8_mid=0, f8_scales=0):
     op = operand_dtype()
     a = IgemmArgs()
     a.M, a.N, a.K, a.a_mode = M, N, K, a_mode
@@ -248,6 +250,7 @@ def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=Non
     a.a_dup_seg = a_dup_seg
     a.a_wrap = a_wrap
     a.bias_row_mod = bias_row_mod
+    a.f8_from, a.f8_mid, a.f8_scales = f8_from, f8_mid, f8_scales
     if ln_out is not None:
         a.ln_weight, a.ln_bias, a.ln_eps = _dev(ln_weight, "ln_weight", torch.float32), _dev(ln_bias, "ln_bias", torch.float32), ln_eps
         a.ln_out, a.ld_ln, a.ln_counter = _dev(ln_out, "ln_out", op), ld_ln, _dev(ln_counter, "ln_counter", torch.int32)

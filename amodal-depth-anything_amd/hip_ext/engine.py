@@ -96,6 +96,40 @@ STAT_CHUNKS = 8
 OC1_COMMUTE = int(os.environ.get("ADA_OC1_COMMUTE", "16"))     # 0: off; 16: operand-typed tap maps (default); 32: fp32 tap maps (no parity gain, slower)
 
 
+# fp8 correction terms (ada_igemm_args.f8_from): a split-precision product whose two small terms x_lo w_hi + x_hi w_lo run on the fp8 matrix pipe
+# (v_mfma_scale_f32_16x16x128_f8f6f4, twice the fp16 rate) -- 2x the MACs' time instead of 3x.  oracle/study_fp8_correction.py: three mantissa bits
+# are enough for terms that are 2^-11 of the product.  ADA_F8_CORR=0 keeps the three fp16 terms everywhere (A/B).
+F8_CORR = os.environ.get("ADA_F8_CORR", "1") != "0"
+F8_A_SCALES = 117 | (127 << 16)     # E8M0 bytes of the activation's two byte segments: lo8 = e5m2((x - x_hi) 2^10), hi8 = e5m2(x)
+
+
+def f8_weight_split(wm: torch.Tensor, op, taps: int = 1):
+    """[N, taps * K] fp32 (K a multiple of 128) -> ([N, taps * 2 K] operand-typed storage, f8_scales word): per tap [w_hi | w_hi8 | w_lo8] with
+    w_hi = round(w) in the operand type (K slots), then K bytes e4m3(w_hi 2^s_hi) and K bytes e4m3((w - w_hi) 2^s_lo), one power-of-two scale per
+    tensor and segment chosen so that the largest magnitude lands in [224, 448].  The contraction against an activation stored [hi | lo8 | hi8]
+    (split_seg = -K) evaluates x_hi w_hi + 2^-10 x_lo8 w_hi8 2^-s_hi + x_hi8 w_lo8 2^-s_lo (include/ada_hip.h, ada_igemm_args.f8_from)."""
+    n = wm.shape[0]
+    k = wm.shape[1] // taps
+    assert wm.shape[1] == taps * k and k % 128 == 0, (wm.shape, taps)
+    w = wm.reshape(n, taps, k).float()
+    hi = w.to(op)
+    lo = w - hi.float()
+
+    def enc(t):
+        m = float(t.abs().max())
+        sh = max(-100, min(100, int(math.floor(math.log2(448.0 / m))))) if m > 0 else 0
+        q = (t.float() * (2.0 ** sh)).clamp(-448.0, 448.0)
+        try:
+            b = q.to(torch.float8_e4m3fn).view(torch.uint8)
+        except (RuntimeError, TypeError):      # no device cast for the dtype on this backend
+            b = q.cpu().to(torch.float8_e4m3fn).view(torch.uint8).to(t.device)
+        return b, 127 - sh
+    hi8, sb_hi = enc(hi)
+    lo8, sb_lo = enc(lo)
+    packed = torch.cat([hi.contiguous().view(torch.uint8).reshape(n, taps, 2 * k), hi8, lo8], dim=2).reshape(n, taps * 4 * k)
+    return packed.contiguous().view(op), F8_A_SCALES | (sb_hi << 8) | (sb_lo << 24)
+
+
 def fused_tail_applies(half, halfp, hi, ho, split):
     """Whether ada_dpt_tail_fwd can take the tail (include/ada_hip.h): single-precision oc2, 64 or 128 (un-padded) channels, and a vertical
     scale whose 10-row halo tiles span at most 7 source row intervals -- always true for the model's 14 / 8 ratio."""
@@ -160,6 +194,10 @@ class PackedWeights:
         # output as [hi | lo] (full three-term product); proj and fc2 / w3 read activations that exist in the operand type only (attention
         # output, MLP hidden) against [w_hi | w_lo] weights (ada_igemm_args.a_wrap: the weight's rounding error goes, the activation's stays).
         self.enc_split_blocks = 0 if self.fold_ln else max(0, min(int(enc_split_blocks), cfg["depth"]))
+        # ... with the two correction terms of qkv / fc1 / w12 on the fp8 matrix pipe where the build has it (fp16 operands, D a multiple of 128)
+        self.enc_f8 = F8_CORR and self.enc_split_blocks > 0 and op == torch.float16 and D % 128 == 0
+        # the taps' [hi | lo] form when they are kept split (own "proj" group, or for the ladder's second rung -- whose weights follow the same rule)
+        self.tap_f8 = F8_CORR and op == torch.float16 and D % 128 == 0
         self.dim, self.depth, self.heads, self.ffn = D, cfg["depth"], cfg["heads"], cfg["ffn"]
 
         def f32(name):
@@ -229,23 +267,27 @@ class PackedWeights:
 
             def lin3(wm):   # [N, K] -> [w_hi | w_hi | w_lo] (against a [hi | lo] activation, a_dup_seg) for the split blocks
                 if not esplit:
-                    return lin(wm)
+                    return lin(wm), 0
+                if self.enc_f8:  # ... or [w_hi | w_hi8 | w_lo8] against [hi | lo8 | hi8] (f8_from): the two correction terms on the fp8 pipe
+                    return f8_weight_split(wm, op)
                 hi_ = wm.to(op)
-                return torch.cat([hi_, hi_, (wm - hi_.float()).to(op)], dim=1).contiguous()
+                return torch.cat([hi_, hi_, (wm - hi_.float()).to(op)], dim=1).contiguous(), 0
 
             def lin2(wm):   # [N, K] -> [w_hi | w_lo] (against a plain activation walked twice, a_wrap)
                 if not esplit:
                     return lin(wm)
                 hi_ = wm.to(op)
                 return torch.cat([hi_, (wm - hi_.float()).to(op)], dim=1).contiguous()
+            qkv_w, qkv_f8 = lin3(qw)
             blk = dict(
                 ln1_w=f32(b + "norm1.weight"), ln1_b=f32(b + "norm1.bias"), esplit=esplit,
-                qkv_w=lin3(qw), qkv_b=qb,
+                qkv_w=qkv_w, qkv_f8=qkv_f8, qkv_b=qb,
                 proj_w=lin2(f32(b + "attn.proj.weight")), proj_b=f32(b + "attn.proj.bias"), ls1=f32(b + "ls1.gamma"),
                 ln2_w=f32(b + "norm2.weight"), ln2_b=f32(b + "norm2.bias"), ls2=f32(b + "ls2.gamma"),
             )
             if self.ffn == "mlp":
-                blk.update(fc1_w=lin3(f32(b + "mlp.fc1.weight")), fc1_b=f32(b + "mlp.fc1.bias"),
+                fc1_w, fc1_f8 = lin3(f32(b + "mlp.fc1.weight"))
+                blk.update(fc1_w=fc1_w, fc1_f8=fc1_f8, fc1_b=f32(b + "mlp.fc1.bias"),
                            fc2_w=lin2(f32(b + "mlp.fc2.weight")), fc2_b=f32(b + "mlp.fc2.bias"))
                 blk["hidden"] = blk["fc1_w"].shape[0]
                 if self.fold_ln:
@@ -263,7 +305,8 @@ class PackedWeights:
                 # interleave x1 / x2 rows in groups of 32 so one wave's two MFMA column tiles hold the gate pair
                 idx = torch.arange(hid, device=w12.device).reshape(-1, 32)
                 order = torch.stack([idx, idx + hid], dim=1).reshape(-1)
-                blk.update(w12_w=lin3(w12[order]), w12_b=b12[order].contiguous(),
+                w12_w, w12_f8 = lin3(w12[order])
+                blk.update(w12_w=w12_w, w12_f8=w12_f8, w12_b=b12[order].contiguous(),
                            w3_w=lin2(f32(b + "mlp.w3.weight")), w3_b=f32(b + "mlp.w3.bias"))
                 blk["hidden"] = hid
             self.blocks.append(blk)
@@ -277,6 +320,18 @@ class PackedWeights:
             lo = (w2d - hi.float()).to(op)
             return torch.cat([hi, hi, lo], dim=-1)
 
+        # Groups whose contractions take their two correction terms on the fp8 pipe (module comment at F8_CORR): the weights are [w_hi | w_hi8 | w_lo8]
+        # per tap, the activation [hi | lo8 | hi8] -- the group's PRODUCERS are told through a negative split_seg (_head: S()).  Needs the operand's
+        # channel count (padded) to be a multiple of 128; a group of another width keeps the three fp16 terms.
+        self.f8_groups = set()
+        f8_ok = F8_CORR and op == torch.float16
+
+        def f8_pack(w2d, group, taps):
+            t, word = f8_weight_split(w2d, op, taps=taps)
+            t.f8_scales = word          # read by DepthEngine._kdup: the packed shape alone does not tell this form from a plain operand
+            self.f8_groups.add(group)
+            return t
+
         def lin(w, group):  # noqa: F811
             if group not in self.split:
                 return lin1(w)
@@ -284,6 +339,9 @@ class PackedWeights:
             k = w.shape[1]
             if k % 64:
                 w = F.pad(w, (0, _r64(k) - k))
+            if f8_ok and w.shape[1] % 128 == 0:
+                return f8_pack(w, group, 1)
+            assert group not in self.f8_groups, group
             return triple(w).contiguous()
 
         def conv3(w, group):  # noqa: F811  [Co, Ci, 3, 3] -> [Co, 9 * 3 * Cip]: per tap [hi | hi | lo]
@@ -293,6 +351,9 @@ class PackedWeights:
             w = w.permute(0, 2, 3, 1)
             if ci % 64:
                 w = F.pad(w, (0, _r64(ci) - ci))
+            if f8_ok and w.shape[-1] % 128 == 0:
+                return f8_pack(w.reshape(co, -1), group, 9)
+            assert group not in self.f8_groups, group
             return triple(w).reshape(co, -1).contiguous()
 
         def convT(w, b, s_, group):  # noqa: F811  [Ci, Co, s, s] -> [s*s*Co, Cip], bias expanded to [s*s*Co]
@@ -424,7 +485,7 @@ class Workspace:
             return 2 if group in pw_.split else 1
         # the taps are [hi | lo] when the projects read them in split precision -- or when the engine keeps them so for the ladder's second rung
         m = 2 if (pw_.tap_split or "proj" in pw_.split) else 1
-        self.tap_seg = D if m == 2 else 0
+        self.tap_seg = (-D if pw_.tap_f8 else D) if m == 2 else 0     # < 0: the [hi | lo8 | hi8] form (ada_igemm_args.f8_from)
         first = "ip" if pw_.amodal_head else "rn"     # the contraction family that reads the reassembled maps L[i]
 
         def z(*shape, dtype=op):
@@ -619,6 +680,16 @@ class DepthEngine:
         operand (K == taps * a_width) or a split one -- [hi | lo] activations against [w_hi | w_hi | w_lo] weights, 2 K == 3 taps a_width,
         the third k segment re-reading the first (ada_igemm a_dup_seg)."""
         K = int(w.shape[1])
+        word = getattr(w, "f8_scales", 0)
+        if word:      # [w_hi | w_hi8 | w_lo8] per tap against [hi | lo8 | hi8] rows: a straight walk whose second half goes to the fp8 pipe (ada_igemm_args.f8_from)
+            seg = abs(a_seg) or a_width // 2
+            if K != 2 * taps * seg or (a_seg > 0):
+                raise HipExtError(f"fp8-form weights with K={K} do not fit an operand with segments of {a_seg or seg} ({taps} tap(s))")
+            return dict(K=K, lda=a_width, f8_from=seg, f8_mid=seg + seg // 2, f8_scales=word)
+        if a_seg < 0:
+            if K == 3 * -a_seg:
+                raise HipExtError("three-term fp16 weights against a [hi | lo8 | hi8] operand")
+            a_seg = -a_seg
         if a_seg:     # the A rows ARE [hi | lo] segments of width a_seg (a tap of an engine that keeps them so): the weights decide what is walked
             if K == 3 * a_seg:
                 return dict(K=K, lda=a_width, a_dup_seg=a_seg)
@@ -640,7 +711,7 @@ class DepthEngine:
         """3x3 conv over a zero-bordered NHWC tensor (plain or split input, see _kdup)."""
         B, Hp, Wp, Cp = src_pad.shape
         kd = cls._kdup(Cp, w, taps=9)
-        k_igemm(M=M, N=N, k_alg=k_alg if k_alg is not None else 9 * (cin or (kd["a_dup_seg"] or Cp)), A=src_pad, W=w, a_mode=A_CONV3,
+        k_igemm(M=M, N=N, k_alg=k_alg if k_alg is not None else 9 * (cin or kd.get("a_dup_seg") or kd.get("f8_from") or Cp), A=src_pad, W=w, a_mode=A_CONV3,
                 conv=(grid[0], grid[1], Hp, Wp, stride), **kd, **kw)
 
     def forward(self, x: torch.Tensor, guide: Optional[torch.Tensor], normalise: Optional[bool] = None) -> torch.Tensor:
@@ -779,14 +850,18 @@ class DepthEngine:
         G = D // 64
         ldy = ws.y.shape[1]
 
-        def a_ln(blk_, wname):      # A-operand arguments of a linear layer that reads the LayerNorm output ws.y: plain, or [hi | lo] in a split block
-            return dict(K=3 * D, lda=ldy, a_dup_seg=D) if blk_["esplit"] else dict(K=D, lda=ldy)
+        def a_ln(blk_, wname):      # A-operand arguments of a linear layer that reads the LayerNorm output ws.y: plain, or [hi | lo] / [hi | lo8 | hi8] in a split block
+            if not blk_["esplit"]:
+                return dict(K=D, lda=ldy)
+            if w.enc_f8:
+                return dict(K=2 * D, lda=ldy, f8_from=D, f8_mid=D + D // 2, f8_scales=blk_[wname.replace("_w", "_f8")])
+            return dict(K=3 * D, lda=ldy, a_dup_seg=D)
 
         def a_act(blk_, kin):       # ... that reads an operand-typed activation of width kin: plain, or walked twice against [w_hi | w_lo]
             return dict(K=2 * kin, lda=kin, a_wrap=kin) if blk_["esplit"] else dict(K=kin, lda=kin)
 
         def seg(blk_):              # split_seg of the LayerNorm that feeds blk_'s linear layers
-            return D if blk_["esplit"] else 0
+            return (-D if w.enc_f8 else D) if blk_["esplit"] else 0
         def lntail(blk_, wk, bk):   # LayerNorm-tail arguments of a proj / fc2 launch whose output rows feed LayerNorm (blk_[wk], blk_[bk]) -> ws.y
             # (the tail lives in the 256x256 tile's kernel: only where the tile heuristic takes that tile anyway -- at least a full round of tiles)
             if not LN_TAIL or blk_["esplit"] or D > 1536 or T < 16384:
@@ -872,7 +947,7 @@ class DepthEngine:
         first = "ip" if w.amodal_head else "rn"     # the family of the contraction that reads the reassembled maps L[i]
 
         def S(group, seg):   # split_seg argument of a producer whose CONSUMER (a contraction of `group`) reads [hi | lo] segments of width seg
-            return seg if group in w.split else 0
+            return (-seg if group in w.f8_groups else seg) if group in w.split else 0     # < 0: [hi | lo8 | hi8]
 
         taps_in = ws.taps
         if w.readout:   # x = GELU(W_x x + (W_cls cls_b + b))  per image (DA2/dpt.py:164-167)

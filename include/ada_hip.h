@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADA_ABI_VERSION 6   /* 6 (round 5): + ada_depth_stats_fwd, ada_token_diversity_fwd (additions only; every ABI-5 entry point and struct layout unchanged) */
+#define ADA_ABI_VERSION 7   /* 6 (round 5): + ada_depth_stats_fwd, ada_token_diversity_fwd; 7: ada_igemm_args grows f8_from / f8_mid / f8_scales at its end and split_seg < 0 names the fp8 form of a split output (a zero-filled tail = off: every ABI-6 call means what it meant) */
 
 /* status codes */
 #define ADA_OK 0
@@ -132,7 +132,8 @@ typedef struct ada_igemm_args {
     const float* ln_colsum; /* LNFOLD: fp32 [N], sum over k of the operand-typed, gain-folded weights W'[n, k] */
     float* rowstat_out;     /* ROWSTATS: fp32 [M, N/64, 2], (sum, sum of squares) of the fp32 result over each 64-column group */
     int32_t split_seg;      /* > 0: split-precision op output -- out_op receives [hi | lo] in two column segments of
-                               split_seg elements (hi = round(v), lo = round(v - hi)); 0 = plain */
+                               split_seg elements (hi = round(v), lo = round(v - hi)); 0 = plain;
+                               < 0: the fp8 form of the same, seg = -split_seg: [hi: seg elements | lo8: seg bytes | hi8: seg bytes], see f8_from */
     int32_t a_dup_seg;      /* > 0: the A operand is such a split tensor: [hi | lo] segments of a_dup_seg elements per row (per tap of a
                                3x3 conv) and the contraction runs over THREE segments (hi, lo, hi -- the third re-reads the first) against
                                weights packed [w_hi | w_hi | w_lo]: x_hi w_hi + x_lo w_hi + x_hi w_lo.  K = 3 * a_dup_seg (x 9 for CONV3),
@@ -164,6 +165,17 @@ typedef struct ada_igemm_args {
     void* ln_out;
     int64_t ld_ln;
     void* ln_counter;
+    /* fp8 correction terms of a split-precision product (gfx950 v_mfma_scale_f32_16x16x128_f8f6f4, twice the fp16 matrix rate):
+         x w  ~  x_hi w_hi  +  2^-10 x_lo8 w_hi8  +  x_hi8 w_lo8          (instead of three fp16 products, a_dup_seg)
+       f8_from > 0: inside each period of the k-walk -- all K operand slots of a PLAIN operand, one tap (lda slots) of a CONV3 one -- the slots from
+       f8_from on hold BYTES, two codes per slot: e5m2 for A, e4m3 for W, contracted 128 codes per k-step into the same fp32 accumulators.
+       Slots [f8_from, f8_mid) use the scale pair in bits 0-15 of f8_scales (A byte, then W byte), [f8_mid, period) the pair in bits 16-31; a scale
+       byte e multiplies its operand by 2^(e - 127) (E8M0).  The A layout [hi: seg slots | lo8: seg bytes | hi8: seg bytes] is what a producer writes
+       for split_seg = -seg (lo8 = e5m2((v - hi) 2^10), hi8 = e5m2(v)); the weights are packed [w_hi | w_hi8 | w_lo8] with per-tensor power-of-two
+       scales: K = 2 seg (x 9), f8_from = seg, f8_mid = 3 seg / 2, f8_scales = 117 | sb_hi << 8 | 127 << 16 | sb_lo << 24.  f8_from, f8_mid: multiples
+       of 64.  Excludes a_dup_seg / a_wrap / EP_LNFOLD.  0 = off */
+    int32_t f8_from, f8_mid;
+    uint32_t f8_scales;
 } ada_igemm_args;
 
 int ada_igemm(const ada_igemm_args* args, void* stream);

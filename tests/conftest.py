@@ -22,3 +22,15 @@ def hip():
     hip_ext.load()
     assert torch.cuda.is_available(), "GPU test selected but no HIP device is visible"
     return hip_ext
+
+
+@pytest.fixture
+def forced_tile(hip):
+    """force(cfg, variant): pins ada_igemm's tile configuration / main-loop variant for the test (debug hooks of the library), restored afterwards."""
+    def force(cfg, variant):
+        hip.debug_set_tile(cfg)
+        hip.debug_set_variant(variant)
+    yield force
+    hip.debug_set_tile(-1)
+    hip.debug_set_variant(0)
+    hip.debug_set_group(0)

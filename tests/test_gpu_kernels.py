@@ -681,17 +681,6 @@ def test_patchify_split_precision(hip):
 TILE_CASES = [(0, 4), (1, 4), (2, 4), (3, 4), (3, 16), (4, 4)]   # (tile cfg, main-loop variant: 4 single barrier, 8 phased)
 
 
-@pytest.fixture
-def forced_tile(hip):
-    def force(cfg, variant):
-        hip.debug_set_tile(cfg)
-        hip.debug_set_variant(variant)
-    yield force
-    hip.debug_set_tile(-1)
-    hip.debug_set_variant(0)
-    hip.debug_set_group(0)
-
-
 def _check_tile(hip, cfg, variant):
     code = hip.debug_last_tile()
     assert code % 100 == cfg, f"forced tile {cfg} but the launch used {code}"

@@ -99,7 +99,9 @@ OC1_COMMUTE = int(os.environ.get("ADA_OC1_COMMUTE", "16"))     # 0: off; 16: ope
 # fp8 correction terms (ada_igemm_args.f8_from): a split-precision product whose two small terms x_lo w_hi + x_hi w_lo run on the fp8 matrix pipe
 # (v_mfma_scale_f32_16x16x128_f8f6f4, twice the fp16 rate) -- 2x the MACs' time instead of 3x.  oracle/study_fp8_correction.py: three mantissa bits
 # are enough for terms that are 2^-11 of the product.  ADA_F8_CORR=0 keeps the three fp16 terms everywhere (A/B).
-F8_CORR = os.environ.get("ADA_F8_CORR", "1") != "0"
+_F8_ENV = os.environ.get("ADA_F8_CORR", "1")     # 1 | 0 | enc | head (A/B: only the encoder's split blocks / only the head's split groups)
+F8_CORR = _F8_ENV != "0"
+F8_ENC, F8_HEAD = _F8_ENV in ("1", "enc"), _F8_ENV in ("1", "head")
 F8_A_SCALES = 117 | (127 << 16)     # E8M0 bytes of the activation's two byte segments: lo8 = e5m2((x - x_hi) 2^10), hi8 = e5m2(x)
 
 
@@ -161,7 +163,8 @@ class PackedWeights:
     with the *raw* model's key names (``pretrained.*``, ``depth_head.*``)."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], encoder: str, guided: bool, amodal_head: bool, split_head=False,
-                 fold_ln: bool = False, enc_split_blocks: int = 0, head_only: bool = False, tap_split: bool = False):
+                 fold_ln: bool = False, enc_split_blocks: int = 0, head_only: bool = False, tap_split: bool = False,
+                 f8: str = "both", tap_f8: Optional[bool] = None):
         op = operand_dtype()
         # head_only: the DPT head's weights only (the second rung of the precision ladder, DepthEngine._escalate, re-runs the head from the taps)
         # tap_split: the four taps are stored [hi | lo] whatever the head's own policy -- so that a split-precision head can be re-run from them
@@ -195,9 +198,14 @@ class PackedWeights:
         # output, MLP hidden) against [w_hi | w_lo] weights (ada_igemm_args.a_wrap: the weight's rounding error goes, the activation's stays).
         self.enc_split_blocks = 0 if self.fold_ln else max(0, min(int(enc_split_blocks), cfg["depth"]))
         # ... with the two correction terms of qkv / fc1 / w12 on the fp8 matrix pipe where the build has it (fp16 operands, D a multiple of 128)
-        self.enc_f8 = F8_CORR and self.enc_split_blocks > 0 and op == torch.float16 and D % 128 == 0
-        # the taps' [hi | lo] form when they are kept split (own "proj" group, or for the ladder's second rung -- whose weights follow the same rule)
-        self.tap_f8 = F8_CORR and op == torch.float16 and D % 128 == 0
+        # f8: which of the two users take it -- "both" | "enc" | "head" | "none" (the caller's precision policy, DA2/dpt.py::_f8_policy)
+        if f8 not in ("both", "enc", "head", "none"):
+            raise HipExtError(f"PackedWeights: f8={f8!r} (both | enc | head | none)")
+        self.f8_head = F8_HEAD and f8 in ("both", "head") and op == torch.float16
+        self.enc_f8 = F8_ENC and f8 in ("both", "enc") and self.enc_split_blocks > 0 and op == torch.float16 and D % 128 == 0
+        # the form of the taps when they are kept split: that of their reader -- this object's own "proj" group, or (tap_f8 given) the weights of
+        # the ladder's second rung, which are packed later from the same state_dict
+        self.tap_f8 = (self.f8_head if tap_f8 is None else (bool(tap_f8) and F8_HEAD and op == torch.float16)) and D % 128 == 0
         self.dim, self.depth, self.heads, self.ffn = D, cfg["depth"], cfg["heads"], cfg["ffn"]
 
         def f32(name):
@@ -324,7 +332,7 @@ class PackedWeights:
         # per tap, the activation [hi | lo8 | hi8] -- the group's PRODUCERS are told through a negative split_seg (_head: S()).  Needs the operand's
         # channel count (padded) to be a multiple of 128; a group of another width keeps the three fp16 terms.
         self.f8_groups = set()
-        f8_ok = F8_CORR and op == torch.float16
+        f8_ok = self.f8_head
 
         def f8_pack(w2d, group, taps):
             t, word = f8_weight_split(w2d, op, taps=taps)
@@ -634,6 +642,7 @@ class DepthEngine:
         self._w_hi: Optional[PackedWeights] = None
         self._ws_hi: "OrderedDict[tuple, Workspace]" = OrderedDict()
         self.escalated = 0            # images the ladder has re-run so far
+        self.tap_f8 = bool(weights.tap_f8)   # the taps (and with them the second rung's products) carry fp8 correction terms
         self.last_ratio = None        # per-image sum s(1-s) / sum s of the most recent call (CPU tensor), None when the ladder is off
         self.last_diversity = None    # per-image token diversity of the last tap (see _escalate)
         self._ws: "OrderedDict[tuple, Workspace]" = OrderedDict()

@@ -194,6 +194,17 @@ def _encoder_split_policy(mode, encoder, final_act):
 # holds ~9e-4 up to r = 0.42 / 0.45; the benchmarked batch has r <= 0.43, the centred noise fixtures r <= 0.41.  Second trigger: token diversity of the last
 # tap below _LADDER_DIV (constant / checkerboard inputs: 0.02; everything else >= 0.23), where rounding errors add coherently over positions.
 # ADA_LADDER_R overrides the threshold ("0" / "off" disables the ladder).
+# Where the two correction terms of a split-precision product run on the fp8 matrix pipe instead of the fp16 one (hip_ext.engine F8_CORR: 2x the
+# MACs' time instead of 3x; residual operand noise ~2^-14 instead of ~2^-22).  Measured on the reference fixtures (profiles/r05_q_fp8_terms_ab.txt):
+# +1.8 % (encoder blocks) / +0.7 % (head) on the fixtures' rel-L1 in the geometric mean.  Used where a split product is a large share of the step --
+# the raw (ReLU) models: BASELINE config 5 is raw ViT-G, 33.9 -> 36.1 images/s at <= 7.7e-4 -- and on the ladder's second rung (_LADDER_F8); the
+# 'ssi' heads (unbounded logits, the thinnest margins: vitl_ssi_518_heavy 8.6e-4) and the sigmoid models' first rung (whose split groups are 1x1
+# convolutions with K <= 256: nothing to gain) keep all three terms on the fp16 pipe.
+def _f8_policy(final_act):
+    return "both" if final_act == "relu" else "none"
+
+
+_LADDER_F8 = "head"
 _LADDER_R = {"vitb": 0.42, "vitl": 0.45}
 _LADDER_DIV = 0.10
 # What the second rung re-runs in split precision: the whole head -- on ViT-L without the ResidualConvUnit convolutions of the two finest levels (the four
@@ -257,8 +268,9 @@ class _EngineMixin:
         plist = self._param_tensors()
         hp = getattr(self, "head_precision", "auto")
         ladder_r = _ladder_threshold(self, self.encoder, self.depth_head.final_act, hp)
+        f8 = getattr(self, "f8_terms", None) or _f8_policy(self.depth_head.final_act)     # module.f8_terms: "both" | "enc" | "head" | "none" overrides the policy
         stamp = tuple((v.data_ptr(), v._version) for v in plist) + (hp if isinstance(hp, str) else tuple(sorted(hp)), getattr(self, "fold_layernorm", _FOLD_LN_DEFAULT),
-                                                                      getattr(self, "encoder_precision", "auto"), ladder_r)
+                                                                      getattr(self, "encoder_precision", "auto"), ladder_r, f8)
         if getattr(self, "_engine_stamp", None) != stamp:
             sd = {k: v.detach() for k, v in zip(self._engine_pnames, plist)}
             # Head precision policy ("auto"): the DPT head runs in split precision (3x its MACs) where its fp16 operand rounding
@@ -273,12 +285,13 @@ class _EngineMixin:
             enc_split = _encoder_split_policy(getattr(self, "encoder_precision", "auto"), self.encoder, self.depth_head.final_act)
             pw = PackedWeights(sd, self.encoder, guided=guided, amodal_head=amodal_head,
                                split_head=split, fold_ln=bool(getattr(self, "fold_layernorm", _FOLD_LN_DEFAULT)),
-                               enc_split_blocks=enc_split, tap_split=ladder_r is not None)
+                               enc_split_blocks=enc_split, tap_split=ladder_r is not None, f8=f8,
+                               tap_f8=(_LADDER_F8 in ("both", "head")) if ladder_r is not None else None)
             ladder = None
             if ladder_r is not None:
                 encoder = self.encoder
                 groups = tuple(g for g in HEAD_GROUPS if g not in _LADDER_SKIP.get(encoder, ()) and g != "projw")
-                ladder = dict(r=ladder_r, div=_LADDER_DIV, make=lambda: PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=groups, head_only=True))
+                ladder = dict(r=ladder_r, div=_LADDER_DIV, make=lambda: PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=groups, head_only=True, f8=_LADDER_F8))
             object.__setattr__(self, "_engine_obj", DepthEngine(pw, self.depth_head.final_act, bool(getattr(self, "normalise_input", False)), ladder=ladder))
             object.__setattr__(self, "_engine_stamp", stamp)
         return self._engine_obj

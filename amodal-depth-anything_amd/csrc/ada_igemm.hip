@@ -1285,7 +1285,17 @@ static inline double tile_time_cu(long M, long N, long K, int bm, int bn, double
 // main loop of the 256x256 tile: variant 16 forces the hand-scheduled 4-wave loop, 4 the single-barrier 8-wave loop; 0 (default) picks the
 // 4-wave loop where its main loop outweighs its slower prologue / epilogue (measured: k-loops of >= 128 k-tiles)
 // (its scalar A-offset counters assume a monotonic walk: a split operand, whose third k segment re-reads the first, stays on the 8-wave loop)
-static inline bool use_pipe4(const IgemmDev& d) { return d.a_dup_seg == 0 && d.a_wrap == 0 && d.f8_from == 0 && d.tap_cols == 0 && d.ln_out == nullptr && (d.variant >= 16 || (d.variant == 0 && d.K >= 8192)); }
+static inline bool use_pipe4(const IgemmDev& d) {
+    if (d.a_dup_seg != 0 || d.a_wrap != 0 || d.f8_from != 0 || d.tap_cols != 0 || d.ln_out != nullptr) return false;
+    if (d.variant != 0) return d.variant >= 16;
+    if (d.K >= 8192) return true;
+    // With a cheap operand-typed epilogue (bias, SwiGLU: no fp32 output, no residual / LayerScale / GELU / row statistics) the slower epilogue of the
+    // one-wave-per-SIMD loop weighs less and it wins from 24 k-steps on launches of many rounds: raw ViT-G at 8 x 1022^2, w12 (N = 8192, K = 1536)
+    // 966 -> 909 us, qkv 526 -> 515 (profiles/r05_j_config5_shapes.txt).  At K = 1024 (ViT-L: qkv -3 %, fc1 + GELU -7 %) it still loses.
+    const bool cheap = d.a_mode == ADA_A_PLAIN && d.out_f32 == nullptr && d.bias_row_mod == 0 &&
+                       !(d.flags & (ADA_EP_RESIDUAL | ADA_EP_GAMMA | ADA_EP_GELU | ADA_EP_ROWSTATS | ADA_EP_LNFOLD | ADA_EP_RELU_OP));
+    return cheap && d.K >= 1536 && (long)((d.M + 255) / 256) * ((d.N + 255) / 256) >= 2048;
+}
 
 template <int EPI>
 int launch_epi(IgemmDev& d, hipStream_t s, int force) {

@@ -9,6 +9,7 @@ mkdir -p gpurun_out/r5z
 O=$PWD/gpurun_out/r5z
 R=$PWD
 ( time timeout 1800 python -m pytest tests -m gpu -q --durations=0 -p no:cacheprovider 2>&1 | grep -v amdgpu | tail -n 700 ) > $O/gpu_suite.txt 2>&1; tail -n 6 $O/gpu_suite.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu | tail -n 2
 timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q -s -k "golden or batch32" -p no:cacheprovider 2>&1 | grep "rel-L1" | sed 's/^\.//' > $O/parity_vs_reference_goldens.txt; wc -l $O/parity_vs_reference_goldens.txt
 ( time python bench.py > $O/bench_default_flags.json 2> $O/bench_default_flags.err ) 2>&1 | tail -n 3; tail -c 400 $O/bench_default_flags.json
 timeout 900 python tools/run_configs.py 2>&1 | grep -v amdgpu > $O/other_configs.txt; cat $O/other_configs.txt

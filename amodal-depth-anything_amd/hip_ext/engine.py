@@ -164,7 +164,7 @@ class PackedWeights:
 
     def __init__(self, sd: Dict[str, torch.Tensor], encoder: str, guided: bool, amodal_head: bool, split_head=False,
                  fold_ln: bool = False, enc_split_blocks: int = 0, head_only: bool = False, tap_split: bool = False,
-                 f8: str = "both", tap_f8: Optional[bool] = None):
+                 f8: str = "both", tap_f8: Optional[bool] = None, f8_only=None):
         op = operand_dtype()
         # head_only: the DPT head's weights only (the second rung of the precision ladder, DepthEngine._escalate, re-runs the head from the taps)
         # tap_split: the four taps are stored [hi | lo] whatever the head's own policy -- so that a split-precision head can be re-run from them
@@ -202,6 +202,7 @@ class PackedWeights:
         if f8 not in ("both", "enc", "head", "none"):
             raise HipExtError(f"PackedWeights: f8={f8!r} (both | enc | head | none)")
         self.f8_head = F8_HEAD and f8 in ("both", "head") and op == torch.float16
+        self.f8_only = None if f8_only is None else frozenset(f8_only)      # head groups that may take it (None: every split group)
         self.enc_f8 = F8_ENC and f8 in ("both", "enc") and self.enc_split_blocks > 0 and op == torch.float16 and D % 128 == 0
         # the form of the taps when they are kept split: that of their reader -- this object's own "proj" group, or (tap_f8 given) the weights of
         # the ladder's second rung, which are packed later from the same state_dict
@@ -347,7 +348,7 @@ class PackedWeights:
             k = w.shape[1]
             if k % 64:
                 w = F.pad(w, (0, _r64(k) - k))
-            if f8_ok and w.shape[1] % 128 == 0:
+            if f8_ok and (self.f8_only is None or group in self.f8_only) and w.shape[1] % 128 == 0:
                 return f8_pack(w, group, 1)
             assert group not in self.f8_groups, group
             return triple(w).contiguous()
@@ -359,7 +360,7 @@ class PackedWeights:
             w = w.permute(0, 2, 3, 1)
             if ci % 64:
                 w = F.pad(w, (0, _r64(ci) - ci))
-            if f8_ok and w.shape[-1] % 128 == 0:
+            if f8_ok and (self.f8_only is None or group in self.f8_only) and w.shape[-1] % 128 == 0:
                 return f8_pack(w.reshape(co, -1), group, 9)
             assert group not in self.f8_groups, group
             return triple(w).reshape(co, -1).contiguous()

@@ -131,6 +131,20 @@ _FOLD_LN_DEFAULT = _os.environ.get("ADA_FOLD_LN", "0") == "1"
 # round 4: + "oc1" (with the encoder's early blocks in split precision -- _UNBOUNDED_ENC_SPLIT_BLOCKS -- the head's share shows again:
 # profiles/r04_e_raw_vitg_precision.txt)
 _SIGMOID_SPLIT = ("out1", "out2", "out3")
+# Round 5: the first rung's four 1x1 projects run as a FULL split product with fp8 correction terms (hip_ext.engine F8_CORR), read from the taps the
+# ladder keeps [hi | lo8 | hi8] anyway -- instead of ViT-L's weight-only split (same time: 2x the projects' MACs) / nothing on ViT-B (+0.9 % of a bs=8
+# step).  30 sigmoid ViT-B / ViT-L reference fixtures: rel-L1 -2.5 % in the geometric mean, worst 8.93e-4 -> 8.57e-4, the benchmarked batch 5.97e-4 -> 5.74e-4,
+# headline unchanged (52.02 / 52.11 / 52.10 / 52.02 ms alternating): profiles/r05_t_first_rung_projects_fp8.txt.  ADA_RUNG1_PROJ_F8=0: the round-4 policy.
+_RUNG1_PROJ_F8 = _os.environ.get("ADA_RUNG1_PROJ_F8", "1") == "1"
+
+
+def _rung1_proj_f8():
+    """... where the build offers the fp8 terms at all (fp16 operands, not masked by ADA_F8_CORR); otherwise the round-4 policy stands"""
+    if not _RUNG1_PROJ_F8:
+        return False
+    import torch as _torch
+    from hip_ext import engine as _E, operand_dtype as _opdt
+    return _E.F8_HEAD and _opdt() == _torch.float16
 _RAW_VITG_SPLIT = ("oc1", "oc2", "out", "rn1", "rn2", "rn3", "proj", "rs1", "rs3")
 
 
@@ -152,6 +166,8 @@ def _head_split_policy(mode, encoder, final_act):
             # ViT-L also runs its four 1x1 projects against [w_hi | w_lo] weights ("projw", weight-only split: 2x their 0.25 TFLOP per bs=32 step,
             # 0.4 % of it): the heavy-tailed 714 x 1022 stress fixture 8.9e-4 -> 6.9e-4, the benchmarked batch 6.17e-4 -> 5.94e-4; on ViT-B the
             # projects are not where the noise sits (9.0e-4 -> 8.8e-4 on its stress fixture, profiles/r04_r_*), so it keeps the three out_convs only
+            if _rung1_proj_f8():
+                return frozenset(_SIGMOID_SPLIT + ("proj",))
             return frozenset(_SIGMOID_SPLIT + (("projw",) if encoder == "vitl" else ()))
         if final_act == "relu" and encoder == "vitg":
             return frozenset(_RAW_VITG_SPLIT)
@@ -283,9 +299,12 @@ class _EngineMixin:
             split = _head_split_policy(mode, self.encoder, self.depth_head.final_act)
             guided, amodal_head = self.pretrained.has_guidance, hasattr(self.depth_head, "input_projection")
             enc_split = _encoder_split_policy(getattr(self, "encoder_precision", "auto"), self.encoder, self.depth_head.final_act)
+            f8_only = None
+            if ladder_r is not None and f8 == "none" and mode == "auto" and "proj" in split and _rung1_proj_f8():
+                f8, f8_only = "head", ("proj",)
             pw = PackedWeights(sd, self.encoder, guided=guided, amodal_head=amodal_head,
                                split_head=split, fold_ln=bool(getattr(self, "fold_layernorm", _FOLD_LN_DEFAULT)),
-                               enc_split_blocks=enc_split, tap_split=ladder_r is not None, f8=f8,
+                               enc_split_blocks=enc_split, tap_split=ladder_r is not None, f8=f8, f8_only=f8_only,
                                tap_f8=(_LADDER_F8 in ("both", "head")) if ladder_r is not None else None)
             ladder = None
             if ladder_r is not None:

@@ -616,7 +616,7 @@ class _GraphedForward:
 
     def __call__(self, x: torch.Tensor, guide: Optional[torch.Tensor], post=None) -> torch.Tensor:
         # the static input / output buffers are shared by every caller of this shape: copy-in, replay and copy-out are one critical section
-        # (`post(ws, out)`: the engine's precision ladder, which reads the taps this replay left in the graph's workspace)
+        # (`post(ws, out, x, guide)`: the engine's precision ladder, which reads the taps this replay left in the graph's workspace)
         with self.lock:
             self.x.copy_(x)
             if self.guide is not None:
@@ -625,7 +625,7 @@ class _GraphedForward:
                 self.guide.copy_(guide)
             self.graph.replay()
             out = self.out.clone()
-            return out if post is None else post(self.ws, out)
+            return out if post is None else post(self.ws, out, x, guide)
 
 
 class DepthEngine:
@@ -642,7 +642,9 @@ class DepthEngine:
             raise HipExtError("precision ladder: the engine's weights must be packed with tap_split=True")
         self._w_hi: Optional[PackedWeights] = None
         self._ws_hi: "OrderedDict[tuple, Workspace]" = OrderedDict()
-        self.escalated = 0            # images the ladder has re-run so far
+        self._eng3: Optional["DepthEngine"] = None       # third rung: an engine with every encoder block and the whole head in split precision
+        self.escalated = 0            # images the ladder has re-run so far (second + third rung)
+        self.escalated3 = 0           # ... of which on the third rung
         self.tap_f8 = bool(weights.tap_f8)   # the taps (and with them the second rung's products) carry fp8 correction terms
         self.last_ratio = None        # per-image sum s(1-s) / sum s of the most recent call (CPU tensor), None when the ladder is off
         self.last_diversity = None    # per-image token diversity of the last tap (see _escalate)
@@ -735,7 +737,7 @@ class DepthEngine:
         use = mode == "1" or (mode == "auto" and x.shape[0] * x.shape[-2] * x.shape[-1] <= GRAPH_AUTO_PIXELS)
         # replay bypasses the Python wrappers: with a KernelTimer or a tile log attached the launches must be issued one by one
         if not use or instrumented() or torch.cuda.is_current_stream_capturing():
-            return self._escalate(None, self._forward(x, guide, norm))
+            return self._escalate(None, self._forward(x, guide, norm), x, guide, norm)
         # the kernel variant / tile override / fused-tail switch in force at capture time are baked into the graph
         key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device), debug_epoch(), FUSED_TAIL, SUBPIXEL, OC1_COMMUTE, LN_TAIL, norm)
         with self._lock:
@@ -758,10 +760,11 @@ class DepthEngine:
                 while len(self._graphs) > max(1, MAX_GRAPHS):
                     self._graphs.popitem(last=False)
         if g is False:
-            return self._escalate(None, self._forward(x, guide, norm))
-        return g(x, guide, self._escalate if self.ladder is not None else None)
+            return self._escalate(None, self._forward(x, guide, norm), x, guide, norm)
+        return g(x, guide, (lambda ws_, out_, x_, g_: self._escalate(ws_, out_, x_, g_, norm)) if self.ladder is not None else None)
 
-    def _escalate(self, ws: Optional[Workspace], out: torch.Tensor) -> torch.Tensor:
+    def _escalate(self, ws: Optional[Workspace], out: torch.Tensor, x: Optional[torch.Tensor] = None, guide: Optional[torch.Tensor] = None,
+                  norm: Optional[bool] = None) -> torch.Tensor:
         """Second rung of the precision ladder (sigmoid heads).  The default policy runs the DPT head on single fp16 operands and
         counts on the sigmoid to compress the logit error it leaves (~1.2e-3 mean absolute): in the north-star metric mean|a - b| / mean|b| that error
         arrives multiplied by  r = sum s (1 - s) / sum s  of the image -- 0.3-0.5 for maps that span (0, 1), -> 1 for maps concentrated near 0, where the
@@ -773,7 +776,12 @@ class DepthEngine:
         0.23-0.53 on noise and image-like inputs, 0.02 on constant and checkerboard images, where every patch token is the same up to its position
         and the head's rounding errors add coherently over positions (ViT-B, all-zero input at output mean 0.50: 1.29e-3 on the first rung, 3.6e-4 on
         the second; profiles/r05_h_*).  Costs one host read of ~50 floats per image (the forward's only synchronisation); off under stream capture
-        (a caller's own HIP graph cannot hold a data-dependent branch)."""
+        (a caller's own HIP graph cannot hold a data-dependent branch).
+        THIRD RUNG (round 5, held-out draws of the output-range sweep): at the very bottom of the range -- maps averaging 0.03-0.06, r > 0.75 -- nothing is
+        left of the sigmoid's compression and the second rung's own logit error (0.8e-3 ... 1.2e-3, the ENCODER's fp16 operand rounding: ViT-B on a constant
+        image at mean 0.03: 1.1e-3 with the whole head in split precision) is what shows.  Images with r above lad["r3"] are therefore run again as a
+        whole, encoder blocks and head in split precision (lad["make3"]: an engine of its own, built on first use; 1.6e-4 ... 3.7e-4 on the cases that
+        exposed it, profiles/r05_v_third_rung_probe.txt), instead of taking the second rung."""
         lad = self.ladder
         if lad is None:
             return out
@@ -791,7 +799,22 @@ class DepthEngine:
         ratio = st[:, 1] / st[:, 0].clamp_min(1e-300)
         diversity = dv[:, 0] / dv[:, 1].clamp_min(1e-300)
         self.last_ratio, self.last_diversity = ratio, diversity
-        idx = torch.nonzero((ratio > lad["r"]) | (diversity < lad.get("div", 0.0))).flatten()
+        trigger = (ratio > lad["r"]) | (diversity < lad.get("div", 0.0))
+        top = (ratio > lad["r3"]) if ("r3" in lad and x is not None) else torch.zeros_like(trigger)
+        idx3 = torch.nonzero(top).flatten()
+        if idx3.numel() > 0:      # third rung: the whole forward in split precision for these images, straight from the inputs
+            if self._eng3 is None:
+                self._eng3 = lad["make3"]()
+            if idx3.numel() == B:
+                self.escalated += B
+                self.escalated3 += B
+                return self._eng3.forward(x, guide, norm)
+            sel3 = idx3.to(out.device)
+            out3 = self._eng3.forward(x.index_select(0, sel3), None if guide is None else guide.index_select(0, sel3), norm)
+            out.index_copy_(0, sel3, out3)
+            self.escalated += int(idx3.numel())
+            self.escalated3 += int(idx3.numel())
+        idx = torch.nonzero(trigger & ~top).flatten()
         if idx.numel() == 0:
             return out
         if self._w_hi is None:

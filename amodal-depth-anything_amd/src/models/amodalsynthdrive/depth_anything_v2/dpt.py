@@ -221,6 +221,10 @@ def _f8_policy(final_act):
 
 
 _LADDER_F8 = "head"
+# Third rung (round 5; hip_ext.engine.DepthEngine._escalate): r above this -- maps averaging under ~0.1 -- and the image is run again as a whole with every
+# encoder block and the whole head in split precision.  The second rung's own error is 0.8e-3 ... 1.2e-3 of LOGIT error (the encoder's operand rounding), i.e.
+# up to 1.1e-3 in the metric at r = 0.91 (held-out draws of the output-range sweep: ViT-B, constant image, mean 0.03); 1.2e-3 x 0.75 = 9e-4 is where it is handed on.
+_LADDER_R3 = 0.75
 _LADDER_R = {"vitb": 0.42, "vitl": 0.45}
 _LADDER_DIV = 0.10
 # What the second rung re-runs in split precision: the whole head -- on ViT-L without the ResidualConvUnit convolutions of the two finest levels (the four
@@ -300,7 +304,9 @@ class _EngineMixin:
             guided, amodal_head = self.pretrained.has_guidance, hasattr(self.depth_head, "input_projection")
             enc_split = _encoder_split_policy(getattr(self, "encoder_precision", "auto"), self.encoder, self.depth_head.final_act)
             f8_only = None
-            if ladder_r is not None and f8 == "none" and mode == "auto" and "proj" in split and _rung1_proj_f8():
+            # the first rung of the sigmoid ViT-B / ViT-L heads (ladder on or off; an explicit head_precision or f8_terms is the caller's choice)
+            if (getattr(self, "f8_terms", None) is None and mode == "auto" and "proj" in split and self.depth_head.final_act == "sigmoid"
+                    and self.encoder != "vits" and _rung1_proj_f8()):
                 f8, f8_only = "head", ("proj",)
             pw = PackedWeights(sd, self.encoder, guided=guided, amodal_head=amodal_head,
                                split_head=split, fold_ln=bool(getattr(self, "fold_layernorm", _FOLD_LN_DEFAULT)),
@@ -310,7 +316,13 @@ class _EngineMixin:
             if ladder_r is not None:
                 encoder = self.encoder
                 groups = tuple(g for g in HEAD_GROUPS if g not in _LADDER_SKIP.get(encoder, ()) and g != "projw")
-                ladder = dict(r=ladder_r, div=_LADDER_DIV, make=lambda: PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=groups, head_only=True, f8=_LADDER_F8))
+                final_act, norm_in, depth = self.depth_head.final_act, bool(getattr(self, "normalise_input", False)), len(self.pretrained.blocks)
+                every = tuple(g for g in HEAD_GROUPS if g != "projw")
+
+                def third():
+                    return DepthEngine(PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=every, enc_split_blocks=depth, f8="both"), final_act, norm_in)
+                ladder = dict(r=ladder_r, div=_LADDER_DIV, make=lambda: PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=groups, head_only=True, f8=_LADDER_F8),
+                              r3=max(_LADDER_R3, ladder_r), make3=third)
             object.__setattr__(self, "_engine_obj", DepthEngine(pw, self.depth_head.final_act, bool(getattr(self, "normalise_input", False)), ladder=ladder))
             object.__setattr__(self, "_engine_stamp", stamp)
         return self._engine_obj

@@ -351,5 +351,5 @@ def test_sigmoid_heads_across_the_output_range_against_oracle(hip, case):
     eng = model.encoder._engine()
     err = rel_l1(out, ref)
     print(f"{enc} {style} {H}x{W} mean {float(ref.mean()):.3f}: rel-L1 vs oracle = {err:.3e}  (r {float(eng.last_ratio[0]):.2f}, token diversity {float(eng.last_diversity[0]):.2f}, "
-          f"{'second' if eng.escalated else 'first'} rung)")
+          f"{'third' if eng.escalated3 else 'second' if eng.escalated else 'first'} rung)")
     assert torch.isfinite(out).all() and err <= 1e-3

@@ -15,6 +15,10 @@ import test_gpu_fuzz as F
 
 cases = [c for c in F._range_cases(14 * F.FUZZ_SCALE, 2025 + F.FUZZ_SEED) if c[3] <= 0.1]
 extra = [(100 + k, enc, style, 0.03, 126, 154) for k, (enc, style) in enumerate([("vitb", "zeros"), ("vitb", "noise"), ("vitl", "zeros"), ("vitl", "structured"), ("vitb", "checker")])]
+if os.environ.get("PROBE_VITS"):     # ViT-S (whole head in split precision by default, no ladder): the same corner
+    cases = []
+    extra = [(200 + k, "vits", style, mean, H, W) for k, (style, mean, H, W) in enumerate([("zeros", 0.03, 126, 154), ("noise", 0.03, 126, 154), ("structured", 0.03, 266, 322), ("checker", 0.05, 154, 126),
+                                                                                          ("zeros", 0.1, 518, 518), ("structured", 0.06, 518, 518), ("zeros", 0.03, 518, 518), ("noise", 0.5, 126, 154)])]
 POLICIES = [("default (ladder)", {}),
             ("head split, fp16 terms", dict(head_precision="split", f8_terms="none")),
             ("head split, fp8 terms", dict(head_precision="split", f8_terms="head")),
@@ -48,6 +52,7 @@ for (i, enc, style, mean, H, W) in cases + extra:
         with torch.no_grad():
             out = model(x.cuda(), guide_rgb=grgb.cuda(), guide_mask=mask.cuda(), observation=obs.cuda()).cpu()
         if r is None:
-            r = float(model.encoder._engine().last_ratio[0])
+            lr = model.encoder._engine().last_ratio
+            r = float(lr[0]) if lr is not None else float((out * (1 - out)).sum() / out.sum())
         errs.append(rel_l1(out, ref))
     print(f"{enc} {style:10s} {H}x{W} mean {mean:.2f} r {r:.2f}: " + "  ".join(f"{e:.3e}" for e in errs), flush=True)

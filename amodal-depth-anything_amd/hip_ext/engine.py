@@ -799,8 +799,11 @@ class DepthEngine:
         ratio = st[:, 1] / st[:, 0].clamp_min(1e-300)
         diversity = dv[:, 0] / dv[:, 1].clamp_min(1e-300)
         self.last_ratio, self.last_diversity = ratio, diversity
-        trigger = (ratio > lad["r"]) | (diversity < lad.get("div", 0.0))
-        top = (ratio > lad["r3"]) if ("r3" in lad and x is not None) else torch.zeros_like(trigger)
+        flat = diversity < lad.get("div", 0.0)
+        trigger = (ratio > lad["r"]) | flat
+        # constant / checkerboard inputs take the third rung too: their rounding errors add coherently in the ENCODER as well (ViT-B, all-zero image at 126 x 154:
+        # 8.5e-4 with the head in split precision, 2.3e-4 with everything), and what a degenerate input costs does not matter
+        top = ((ratio > lad["r3"]) | flat) if ("r3" in lad and x is not None) else torch.zeros_like(trigger)
         idx3 = torch.nonzero(top).flatten()
         if idx3.numel() > 0:      # third rung: the whole forward in split precision for these images, straight from the inputs
             if self._eng3 is None:

@@ -517,10 +517,14 @@ class Workspace:
         self.taps = [z(P, m * D) for _ in range(4)]
         # the precision ladder's per-image statistics, one buffer (one host read): stat_sums = (sum s, sum s (1 - s)) of the depth map in chunks
         # (ada_depth_stats_fwd), stat_div = (sum of column variances, sum of column mean squares) of the last tap in 64-column chunks (ada_token_diversity_fwd)
+        # ... and stat_in = the same pair over the PATCHIFIED INPUT (a_pe: one row per patch, pixels + guide channels): exactly zero variance when every patch of the
+        # image is the same (constant images, pixel checkerboards) -- the input-side trigger of the flat-input rung
         G = (D + 63) // 64
-        self.stat_buf = z(B * (STAT_CHUNKS + G) * 2, dtype=torch.float32)
+        Gi = 0 if head_only else pw_.pe_seg // 64
+        self.stat_buf = z(B * (STAT_CHUNKS + G + Gi) * 2, dtype=torch.float32)
         self.stat_sums = self.stat_buf[:B * STAT_CHUNKS * 2].view(B, STAT_CHUNKS, 2)
-        self.stat_div = self.stat_buf[B * STAT_CHUNKS * 2:].view(B, G, 2)
+        self.stat_div = self.stat_buf[B * STAT_CHUNKS * 2:B * (STAT_CHUNKS + G) * 2].view(B, G, 2)
+        self.stat_in = self.stat_buf[B * (STAT_CHUNKS + G) * 2:].view(B, Gi, 2) if Gi else None
         if pw_.readout:
             self.cls_op = [z(B, m * D) for _ in range(4)]                          # final-LayerNorm'd class tokens, operand-typed
             self.cls_bias = [z(B, D, dtype=torch.float32) for _ in range(4)]       # W_cls cls + b per image
@@ -637,8 +641,11 @@ class DepthEngine:
         self.normalise_input = normalise_input
         # Precision ladder of the sigmoid heads (see _escalate): dict(r=<threshold on sum s(1-s) / sum s>, make=<callable -> head-only PackedWeights
         # in split precision>) or None.  The first rung -- this engine's own weights -- must keep its taps [hi | lo] (PackedWeights.tap_split).
-        self.ladder = ladder if (ladder is not None and final_act == "sigmoid") else None
-        if self.ladder is not None and not weights.tap_split and "proj" not in weights.split:
+        # Heads without a sigmoid keep the third rung's token-diversity trigger only: dict(div=..., make3=...) (DA2/dpt.py::_flat_input_rung).
+        if ladder is not None and "r" in ladder and final_act != "sigmoid":
+            ladder = None
+        self.ladder = ladder
+        if self.ladder is not None and "make" in self.ladder and not weights.tap_split and "proj" not in weights.split:
             raise HipExtError("precision ladder: the engine's weights must be packed with tap_split=True")
         self._w_hi: Optional[PackedWeights] = None
         self._ws_hi: "OrderedDict[tuple, Workspace]" = OrderedDict()
@@ -648,6 +655,7 @@ class DepthEngine:
         self.tap_f8 = bool(weights.tap_f8)   # the taps (and with them the second rung's products) carry fp8 correction terms
         self.last_ratio = None        # per-image sum s(1-s) / sum s of the most recent call (CPU tensor), None when the ladder is off
         self.last_diversity = None    # per-image token diversity of the last tap (see _escalate)
+        self.last_input_diversity = None   # ... and of the patchified input
         self._ws: "OrderedDict[tuple, Workspace]" = OrderedDict()
         self._graphs: "OrderedDict[tuple, object]" = OrderedDict()   # key -> _GraphedForward | False (capture refused) | int (sightings)
         self._lock = threading.Lock()
@@ -791,19 +799,29 @@ class DepthEngine:
         if ws is None:
             ws = self.workspace(B, H, W, out.device)
         D = self.w.dim
-        k_depth_stats(out, ws.stat_sums)
+        has_r = "r" in lad           # sigmoid heads; the others watch the token diversity only
+        if has_r:
+            k_depth_stats(out, ws.stat_sums)
         k_token_diversity(ws.taps[3], ws.taps[3].shape[1], B, ws.ph * ws.pw, D, ws.stat_div)
-        host = ws.stat_buf.cpu().double()                       # the forward's one synchronisation: (8 + D / 64) x 2 floats per image
-        nst = B * STAT_CHUNKS * 2
-        st, dv = host[:nst].view(B, STAT_CHUNKS, 2).sum(1), host[nst:].view(B, -1, 2).sum(1)
-        ratio = st[:, 1] / st[:, 0].clamp_min(1e-300)
+        if ws.stat_in is not None:
+            k_token_diversity(ws.a_pe, ws.a_pe.shape[1], B, ws.ph * ws.pw, self.w.pe_seg, ws.stat_in)
+        host = ws.stat_buf.cpu().double()                       # the forward's one synchronisation: (8 + D / 64 + patch width / 64) x 2 floats per image
+        nst, ndv = B * STAT_CHUNKS * 2, B * ((D + 63) // 64) * 2
+        st, dv = host[:nst].view(B, STAT_CHUNKS, 2).sum(1), host[nst:nst + ndv].view(B, -1, 2).sum(1)
+        ratio = st[:, 1] / st[:, 0].clamp_min(1e-300) if has_r else torch.zeros(B, dtype=torch.float64)
         diversity = dv[:, 0] / dv[:, 1].clamp_min(1e-300)
         self.last_ratio, self.last_diversity = ratio, diversity
         flat = diversity < lad.get("div", 0.0)
-        trigger = (ratio > lad["r"]) | flat
+        if ws.stat_in is not None:
+            # input-side trigger: the patches of the image are all alike (variance over patches below 1e-4 of their mean square) -- the raw models' last tap does not
+            # tell (synthetic raw ViT-B at 518^2: token diversity 0.18 on an all-zero image, 0.11 on a noise image; profiles/r05_aa_*), the input does
+            di = host[nst + ndv:].view(B, -1, 2).sum(1)
+            self.last_input_diversity = di[:, 0] / di[:, 1].clamp_min(1e-300)
+            flat = flat | (self.last_input_diversity < lad.get("div_in", 1e-4))
+        trigger = ((ratio > lad["r"]) if has_r else torch.zeros_like(flat)) | flat
         # constant / checkerboard inputs take the third rung too: their rounding errors add coherently in the ENCODER as well (ViT-B, all-zero image at 126 x 154:
         # 8.5e-4 with the head in split precision, 2.3e-4 with everything), and what a degenerate input costs does not matter
-        top = ((ratio > lad["r3"]) | flat) if ("r3" in lad and x is not None) else torch.zeros_like(trigger)
+        top = (((ratio > lad["r3"]) if "r3" in lad else torch.zeros_like(flat)) | flat) if ("make3" in lad and x is not None) else torch.zeros_like(trigger)
         idx3 = torch.nonzero(top).flatten()
         if idx3.numel() > 0:      # third rung: the whole forward in split precision for these images, straight from the inputs
             if self._eng3 is None:

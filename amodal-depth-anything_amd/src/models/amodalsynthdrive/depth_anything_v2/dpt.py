@@ -180,7 +180,9 @@ def _head_split_policy(mode, encoder, final_act):
 # Round 4: the encoder's own operand noise.  For the unbounded-output ViT-G model the encoder alone reaches 0.7e-3 ... 1.05e-3 of the 1e-3 budget
 # depending on the weight draw (tests/golden/raw_vitg_224_w1: 1.05e-3 with the WHOLE head in split precision), and half of that is injected by
 # the first quarter of the blocks (later blocks amplify it): their linear layers run in split precision (PackedWeights.enc_split_blocks).
-_UNBOUNDED_ENC_SPLIT_BLOCKS = {"shallow": 4, "deep": 8}
+# (round 5: ViT-S every block -- a raw ViT-S draw on a plain noise input read 1.2e-3 with 4 of its 12 blocks split, 3.4e-4 with all of them,
+#  profiles/r05_aa_*; the model is cheap)
+_UNBOUNDED_ENC_SPLIT_BLOCKS = {"vits": 12, "vitb": 4, "vitl": 8, "vitg": 8}
 
 
 def _encoder_split_policy(mode, encoder, final_act):
@@ -195,7 +197,7 @@ def _encoder_split_policy(mode, encoder, final_act):
         # (ViT-L / G) blocks' linear layers in split precision every one of them is <= 6.1e-4 (ViT-G <= 7.8e-4).  The sigmoid models -- the
         # benchmarked ones -- keep every block in single precision.
         if final_act in ("relu", "none"):
-            return _UNBOUNDED_ENC_SPLIT_BLOCKS["deep" if encoder in ("vitl", "vitg") else "shallow"]
+            return _UNBOUNDED_ENC_SPLIT_BLOCKS[encoder]
         return 0
     return int(mode)
 
@@ -251,6 +253,21 @@ def _ladder_threshold(module, encoder, final_act, mode):
     return float(val) if val else None
 
 
+def _flat_input_rung(module, final_act, mode):
+    """The heads WITHOUT a sigmoid (raw ReLU, 'ssi') keep one rung of the ladder: an image whose patch tokens are all alike (constant / checkerboard input: every
+    patch of the patchified input the same, or token diversity of the last tap under _LADDER_DIV) is run again with every encoder block and the whole head in split precision -- its rounding errors add
+    coherently over positions and nothing compresses them: raw ViT-B on an all-zero 518 x 518 image 1.15e-3 -> 4.7e-4, 'ssi' ViT-B 1.13e-3 -> 4.4e-4, raw ViT-L on
+    a checkerboard 1.14e-3 -> 3.9e-4 (profiles/r05_aa_*).  Off with precision_ladder = False / ADA_LADDER_R = off, or when the caller chose a precision."""
+    if final_act == "sigmoid" or mode != "auto" or _os.environ.get("ADA_HEAD_SPLIT") is not None or getattr(module, "encoder_precision", "auto") != "auto":
+        return False
+    val = getattr(module, "precision_ladder", None)
+    if val is None:
+        val = _os.environ.get("ADA_LADDER_R")
+    if isinstance(val, str):
+        return val.lower() not in ("off", "0", "false", "")
+    return val is not False and val != 0.0
+
+
 class _EngineMixin:
     """Lazily builds / refreshes the packed weights + launch plan whenever a parameter changes."""
 
@@ -290,7 +307,8 @@ class _EngineMixin:
         ladder_r = _ladder_threshold(self, self.encoder, self.depth_head.final_act, hp)
         f8 = getattr(self, "f8_terms", None) or _f8_policy(self.depth_head.final_act)     # module.f8_terms: "both" | "enc" | "head" | "none" overrides the policy
         stamp = tuple((v.data_ptr(), v._version) for v in plist) + (hp if isinstance(hp, str) else tuple(sorted(hp)), getattr(self, "fold_layernorm", _FOLD_LN_DEFAULT),
-                                                                      getattr(self, "encoder_precision", "auto"), ladder_r, f8)
+                                                                      getattr(self, "encoder_precision", "auto"), ladder_r, f8,
+                                                                      _flat_input_rung(self, self.depth_head.final_act, hp if isinstance(hp, str) else "groups"))
         if getattr(self, "_engine_stamp", None) != stamp:
             sd = {k: v.detach() for k, v in zip(self._engine_pnames, plist)}
             # Head precision policy ("auto"): the DPT head runs in split precision (3x its MACs) where its fp16 operand rounding
@@ -323,6 +341,13 @@ class _EngineMixin:
                     return DepthEngine(PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=every, enc_split_blocks=depth, f8="both"), final_act, norm_in)
                 ladder = dict(r=ladder_r, div=_LADDER_DIV, make=lambda: PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=groups, head_only=True, f8=_LADDER_F8),
                               r3=max(_LADDER_R3, ladder_r), make3=third)
+            if ladder is None and _flat_input_rung(self, self.depth_head.final_act, mode):
+                final_act, norm_in, depth, encoder, f8_ = self.depth_head.final_act, bool(getattr(self, "normalise_input", False)), len(self.pretrained.blocks), self.encoder, f8
+
+                def everything():
+                    return DepthEngine(PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=tuple(g for g in HEAD_GROUPS if g != "projw"),
+                                                     enc_split_blocks=depth, f8=f8_), final_act, norm_in)
+                ladder = dict(div=_LADDER_DIV, make3=everything)
             object.__setattr__(self, "_engine_obj", DepthEngine(pw, self.depth_head.final_act, bool(getattr(self, "normalise_input", False)), ladder=ladder))
             object.__setattr__(self, "_engine_stamp", stamp)
         return self._engine_obj

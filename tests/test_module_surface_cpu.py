@@ -117,14 +117,14 @@ def test_product_package_never_imports_the_oracle():
 
 def test_encoder_precision_policy_table(monkeypatch):
     """Which models run the linear layers of their leading transformer blocks in split precision by default ("auto"): every unbounded head -- the
-    raw model's ReLU, the 'ssi' heads (no activation) -- because nothing compresses the encoder's operand noise there: 4 blocks on ViT-S / ViT-B,
+    raw model's ReLU, the 'ssi' heads (no activation) -- because nothing compresses the encoder's operand noise there: every block on ViT-S (round 5), 4 on ViT-B,
     8 on ViT-L / ViT-G (profiles/r04_e_raw_vitg_precision.txt, r04_q_unbounded_heads_encoder_precision.txt); the benchmarked sigmoid models none."""
     from src.models.amodalsynthdrive.depth_anything_v2.dpt import _encoder_split_policy
     monkeypatch.delenv("ADA_ENC_SPLIT", raising=False)
     for enc in ("vits", "vitb", "vitl"):
         assert _encoder_split_policy("auto", enc, "sigmoid") == 0
     for act in ("relu", "none"):
-        assert [_encoder_split_policy("auto", enc, act) for enc in ("vits", "vitb", "vitl", "vitg")] == [4, 4, 8, 8]
+        assert [_encoder_split_policy("auto", enc, act) for enc in ("vits", "vitb", "vitl", "vitg")] == [12, 4, 8, 8]   # (round 5: every block of ViT-S)
     assert _encoder_split_policy(5, "vitl", "sigmoid") == 5
     monkeypatch.setenv("ADA_ENC_SPLIT", "3")
     assert _encoder_split_policy("auto", "vitl", "sigmoid") == 3 and _encoder_split_policy(0, "vitl", "none") == 0

@@ -54,7 +54,7 @@ def main():
         div = float((t3.var(dim=1, unbiased=False).sum(-1) / (t3 * t3).mean(dim=1).sum(-1)).min())
         ratio = eng.last_ratio
         rmax = float(ratio.max()) if ratio is not None else float("nan")
-        nesc = int((ratio > eng.ladder["r"]).sum()) if ratio is not None else 0
+        nesc = int((ratio > eng.ladder.get("r", float("inf"))).sum()) if ratio is not None else 0
         enc.head_precision = "split"
         res["hs"] = run()
         enc.encoder_precision = 8 if case["encoder"] in ("vitl", "vitg") else 4

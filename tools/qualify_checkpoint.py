@@ -101,7 +101,7 @@ def main():
                     extra = ""
                     if name == "default":
                         if eng.last_ratio is not None and eng.ladder is not None:
-                            extra = f" (r {float(eng.last_ratio.max()):.2f}{', rung 2' if float(eng.last_ratio.max()) > eng.ladder['r'] else ''})"
+                            extra = f" (r {float(eng.last_ratio.max()):.2f}{', rung 2' if float(eng.last_ratio.max()) > eng.ladder.get('r', float('inf')) else ''})"
                         guide = None if a.raw else model.build_guide(grgb.cuda(), mask.cuda(), obs.cuda())
                         _, rep = eng.saturation_report(x.cuda(), guide)
                         if rep:

@@ -229,6 +229,7 @@ _LADDER_F8 = "head"
 _LADDER_R3 = 0.75
 _LADDER_R = {"vitb": 0.42, "vitl": 0.45}
 _LADDER_DIV = 0.10
+_LADDER_DIV_IN = 1e-4      # variance of the patchified input over the image's patches / their mean square: 0 for constant images and pixel checkerboards, ~0.25-1 otherwise
 # What the second rung re-runs in split precision: the whole head -- on ViT-L without the ResidualConvUnit convolutions of the two finest levels (the four
 # 148^2 and four 74^2 convs: 23 % of the rung's MACs): on the five low-mean / constant ViT-L fixtures that subset is as good or better (5.8-6.5e-4 against
 # 5.4-7.5e-4 with everything split, profiles/r05_h_ladder_second_rung_subsets.txt); ViT-B needs them (8.5e-4 against 9.9e-4 on its worst fixture).
@@ -255,7 +256,7 @@ def _ladder_threshold(module, encoder, final_act, mode):
 
 def _flat_input_rung(module, final_act, mode):
     """The heads WITHOUT a sigmoid (raw ReLU, 'ssi') keep one rung of the ladder: an image whose patch tokens are all alike (constant / checkerboard input: every
-    patch of the patchified input the same, or token diversity of the last tap under _LADDER_DIV) is run again with every encoder block and the whole head in split precision -- its rounding errors add
+    patch of the patchified input the same: _LADDER_DIV_IN) is run again with every encoder block and the whole head in split precision -- its rounding errors add
     coherently over positions and nothing compresses them: raw ViT-B on an all-zero 518 x 518 image 1.15e-3 -> 4.7e-4, 'ssi' ViT-B 1.13e-3 -> 4.4e-4, raw ViT-L on
     a checkerboard 1.14e-3 -> 3.9e-4 (profiles/r05_aa_*).  Off with precision_ladder = False / ADA_LADDER_R = off, or when the caller chose a precision."""
     if final_act == "sigmoid" or mode != "auto" or _os.environ.get("ADA_HEAD_SPLIT") is not None or getattr(module, "encoder_precision", "auto") != "auto":
@@ -347,7 +348,8 @@ class _EngineMixin:
                 def everything():
                     return DepthEngine(PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=tuple(g for g in HEAD_GROUPS if g != "projw"),
                                                      enc_split_blocks=depth, f8=f8_), final_act, norm_in)
-                ladder = dict(div=_LADDER_DIV, make3=everything)
+                # (input-side trigger only: the raw models' last tap does not tell -- synthetic raw ViT-G reads a token diversity of 0.09 on a small NOISE image)
+                ladder = dict(div_in=_LADDER_DIV_IN, make3=everything)
             object.__setattr__(self, "_engine_obj", DepthEngine(pw, self.depth_head.final_act, bool(getattr(self, "normalise_input", False)), ladder=ladder))
             object.__setattr__(self, "_engine_stamp", stamp)
         return self._engine_obj

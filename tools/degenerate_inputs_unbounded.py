@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """The models WITHOUT a sigmoid (raw ReLU heads, 'ssi' heads) on constant / checkerboard inputs, where every patch token is the same up to its position and
 rounding errors add coherently -- the corner that needed the third rung on the sigmoid heads.  Whole model against the CPU oracle run on the box, small sizes.
+PROBE_UNCENTRED=1 leaves the raw models' synthetic logits where they fall (most of the ReLU map clipped to zero: the metric's ill-conditioned corner).
 Measurement tool (GPU box)."""
 import os
 import sys
@@ -31,7 +32,7 @@ def main():
         model = build_product_model(spec)
         for wseed in (0, 1):
             sd = synth_state_dict(model, seed=wseed)
-            if spec["kind"] == "raw":      # as the reference fixtures do (oracle/make_golden.py): the logits of the NOISE input centred at +1.5, most of the map positive
+            if spec["kind"] == "raw" and not os.environ.get("PROBE_UNCENTRED"):      # as the reference fixtures do (oracle/make_golden.py): the logits of the NOISE input centred at +1.5, most of the map positive
                 tr = {}
                 oracle_forward(sd, spec, make_inputs(1, spec["H"], spec["W"], spec["seed"], style="noise")[0], None, None, None, trace=tr)
                 key = "depth_head.scratch.output_conv2.2.bias"

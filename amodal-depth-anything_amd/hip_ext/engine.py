@@ -783,7 +783,7 @@ class DepthEngine:
         of the last tap (ada_token_diversity_fwd: sum of the feature columns' variances over the image's patch tokens / sum of their mean squares) --
         0.23-0.53 on noise and image-like inputs, 0.02 on constant and checkerboard images, where every patch token is the same up to its position
         and the head's rounding errors add coherently over positions (ViT-B, all-zero input at output mean 0.50: 1.29e-3 on the first rung, 3.6e-4 on
-        the second; profiles/r05_h_*).  Costs one host read of ~50 floats per image (the forward's only synchronisation); off under stream capture
+        the second; profiles/r05_h_*) -- such an image now goes to the THIRD rung, below.  Costs one host read of ~50 floats per image (the forward's only synchronisation); off under stream capture
         (a caller's own HIP graph cannot hold a data-dependent branch).
         THIRD RUNG (round 5, held-out draws of the output-range sweep): at the very bottom of the range -- maps averaging 0.03-0.06, r > 0.75 -- nothing is
         left of the sigmoid's compression and the second rung's own logit error (0.8e-3 ... 1.2e-3, the ENCODER's fp16 operand rounding: ViT-B on a constant

@@ -28,9 +28,13 @@ def main():
     specs += [dict(kind="amodal", encoder=e, guide_type="mask+observation", loss="invisible_part_ssi", B=1, H=126, W=154, seed=910 + i) for i, e in enumerate(("vits", "vitb", "vitl"))]
     specs += [dict(kind="raw", encoder="vitb", features=128, out_channels=RAW["vitb"][1], B=1, H=518, W=518, seed=920),
               dict(kind="amodal", encoder="vitb", guide_type="mask+observation", loss="invisible_part_ssi", B=1, H=518, W=518, seed=921)]
+    draws = os.environ.get("PROBE_DRAWS")
+    if draws:      # more weight draws on plain inputs (the raw ViT-S draw that 4 split blocks did not hold came from here): no degenerate inputs, two sizes
+        specs = [dict(kind="raw", encoder=e, features=RAW[e][0], out_channels=RAW[e][1], B=1, H=H, W=W, seed=940 + i) for i, e in enumerate(("vits", "vitb", "vitl")) for (H, W) in ((126, 154), (266, 322))]
+        specs += [dict(kind="amodal", encoder=e, guide_type="mask+observation", loss="invisible_part_ssi", B=1, H=126, W=154, seed=950 + i) for i, e in enumerate(("vits", "vitb", "vitl"))]
     for spec in specs:
         model = build_product_model(spec)
-        for wseed in (0, 1):
+        for wseed in ((2, 3, 4, 5) if draws else (0, 1)):
             sd = synth_state_dict(model, seed=wseed)
             if spec["kind"] == "raw" and not os.environ.get("PROBE_UNCENTRED"):      # as the reference fixtures do (oracle/make_golden.py): the logits of the NOISE input centred at +1.5, most of the map positive
                 tr = {}
@@ -39,7 +43,7 @@ def main():
                 sd[key] = sd[key] - (float(tr["logits"].mean()) - 1.5)
             model.load_state_dict(sd, strict=True)
             model = model.cuda()
-            for style in ("noise", "zeros", "checker"):
+            for style in (("noise", "structured") if draws else ("noise", "zeros", "checker")):
                 x, grgb, mask, obs = make_inputs(1, spec["H"], spec["W"], spec["seed"], style=style)
                 holder = model if spec["kind"] == "raw" else model.encoder      # the module that carries the engine's policy attributes
                 ref = oracle_forward(sd, spec, x, None, None, None) if spec["kind"] == "raw" else oracle_forward(sd, spec, x, grgb, mask, obs)

@@ -89,8 +89,11 @@ def main():
                     dict(model.named_parameters())[bias_key].copy_(sd2[bias_key])
                 ref = oracle_forward(sd2, case, x, grgb, mask, obs)
                 line = f"{H:4d}x{W:<4d} {style + tag:22s} ref mean {float(ref.mean()):6.3f} |"
-                for name, head, encp in (("default", "auto", "auto"), ("head split", "split", "auto"), ("head + encoder split", "split", 8 if a.encoder in ("vitl", "vitg") else 4)):
+                for name, head, encp in (("default", "auto", "auto"), ("head split", "split", "auto"), ("head + encoder split", "split", 8 if a.encoder in ("vitl", "vitg") else 4),
+                                         ("head + every encoder block split", "split", 99)):
                     enc.head_precision, enc.encoder_precision = head, encp
+                    eng0 = enc._engine()
+                    n2, n3 = eng0.escalated, eng0.escalated3
                     with torch.no_grad():
                         if a.raw:
                             out = model(x.cuda()).cpu()
@@ -101,7 +104,8 @@ def main():
                     extra = ""
                     if name == "default":
                         if eng.last_ratio is not None and eng.ladder is not None:
-                            extra = f" (r {float(eng.last_ratio.max()):.2f}{', rung 2' if float(eng.last_ratio.max()) > eng.ladder.get('r', float('inf')) else ''})"
+                            rung = ", rung 3" if eng.escalated3 > n3 else (", rung 2" if eng.escalated > n2 else "")
+                            extra = f" (r {float(eng.last_ratio.max()):.2f}{rung})"
                         guide = None if a.raw else model.build_guide(grgb.cuda(), mask.cuda(), obs.cuda())
                         _, rep = eng.saturation_report(x.cuda(), guide)
                         if rep:

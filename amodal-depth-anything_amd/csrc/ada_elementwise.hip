@@ -619,23 +619,6 @@ __global__ __launch_bounds__(256) void pos_embed_resize_kernel(const float* __re
     ((float4*)(out + (long)tok * dim))[c] = acc;
 }
 
-// (mean, rstd) per row from the per-group partial sums of an ADA_EP_ROWSTATS epilogue: one thread per row, fp32, fixed summation order
-__global__ __launch_bounds__(256) void rowstats_finalize_kernel(const float* __restrict__ partials, int rows, int groups, float eps, float* __restrict__ stats) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    const float2* src = (const float2*)(partials + (long)r * groups * 2);
-    float s1 = 0.0f, s2 = 0.0f;
-    for (int g = 0; g < groups; ++g) {
-        const float2 v = src[g];
-        s1 += v.x;
-        s2 += v.y;
-    }
-    const float inv_n = 1.0f / (float)(groups * 64);
-    const float mean = s1 * inv_n;
-    const float var = __builtin_fmaxf(s2 * inv_n - mean * mean, 0.0f);
-    *(float2*)(stats + (long)r * 2) = make_float2(mean, 1.0f / sqrtf(var + eps));
-}
-
 }  // namespace
 
 extern "C" int ada_pos_embed_resize(const float* pos, int32_t sq, int32_t dim, int32_t ph, int32_t pw, double scale_h, double scale_w, float* out,
@@ -645,12 +628,6 @@ extern "C" int ada_pos_embed_resize(const float* pos, int32_t sq, int32_t dim, i
     hipLaunchKernelGGL(pos_embed_resize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, sq, dim, ph, pw,
                        (float)(1.0 / scale_h), (float)(1.0 / scale_w), out);
     return ada_check_launch("ada_pos_embed_resize");
-}
-
-extern "C" int ada_rowstats_finalize(const float* partials, int32_t rows, int32_t groups, float eps, float* stats, void* stream) {
-    ADA_REQUIRE(partials && stats && rows > 0 && groups > 0, ADA_EINVAL, "ada_rowstats_finalize: bad arguments");
-    hipLaunchKernelGGL(rowstats_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, rows, groups, eps, stats);
-    return ada_check_launch("ada_rowstats_finalize");
 }
 
 static std::atomic<int> g_ln_lpr{[]() { const char* e = getenv("ADA_LN_LPR"); return e ? atoi(e) : 0; }()};   // experiment switch: 64 = always one wave per row

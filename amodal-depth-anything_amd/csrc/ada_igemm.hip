@@ -40,12 +40,6 @@ enum { EPI_STD = 0, EPI_GELU = 1, EPI_SHUFFLE = 2, EPI_SWIGLU = 3, EPI_TAIL = 4 
 #ifndef ADA_EPI_NT
 #define ADA_EPI_NT 4
 #endif
-#ifndef ADA_EPI_WT
-#define ADA_EPI_WT 0          // experiment: 1 = the fp32 residual-stream stores of the proj / fc2 epilogues are write-through (sc1) also without a LayerNorm tail
-#endif
-#ifndef ADA_LN_TAIL_PLAIN
-#define ADA_LN_TAIL_PLAIN 0   // experiment switch of the LayerNorm tail's reader: 1 = agent-scope acquire + plain loads, 0 = sc1 loads
-#endif
 ADA_DEV float4 ld_res4(const float* ptr) {
 #if ADA_EPI_NT & 1
     const f32x4 v = __builtin_nontemporal_load((const f32x4*)ptr);
@@ -53,13 +47,6 @@ ADA_DEV float4 ld_res4(const float* ptr) {
 #else
     return *(const float4*)ptr;
 #endif
-}
-// 16-byte fp32 store that is written through to memory (sc1): the form in which a tile publishes its rows to another workgroup of the SAME
-// launch (the LayerNorm tail below) -- cdna_hip_programming.md section 6, Guideline 16 R1 ("sc1 stores -> every wave s_waitcnt vmcnt(0) ->
-// __syncthreads() -> relaxed agent-scope ticket; the reader loads sc1").  A plain store would stay in this XCD's L2, invisible to a reader on another XCD.
-ADA_DEV void st_f32x4_wt(float* ptr, float4 v) {
-    const f32x4 t = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(t) : "memory");
 }
 ADA_DEV void st_f32x4(float* ptr, float4 v) {
 #if ADA_EPI_NT & 2
@@ -93,22 +80,11 @@ struct IgemmDev {
     int map_h, map_w;
     FastDiv dMapW, dMapHW;
     int shuffle_s, shuffle_c;
-    const float* ln_stats;    // EP_LNFOLD: per-row (mean, rstd) of the un-normalised A operand
-    const float* ln_colsum;   // EP_LNFOLD: per-column sum of the (gain-folded) weights
-    float* rowstat_out;       // EP_ROWSTATS: partial (sum, sum of squares) of the fp32 output per row and 64-column group
-    int rowstat_groups;       // N / 64
     int split_seg;   // > 0: the op-typed output is written as [hi | lo] in two column segments of this width (split precision)
     int a_dup_seg;   // > 0: the A operand is a [hi | lo] split tensor contracted as (hi, lo, hi) against [w_hi | w_hi | w_lo] weights
     int split_f8;    // the split output is [hi | lo8 | hi8] (bytes behind the hi segment) instead of [hi | lo]
     int f8_from, f8_mid;   // k-steps (inside a period of the k-walk: all of K, or one conv tap) from which the operands are fp8 bytes / the scale pair changes; 0 = off
     unsigned f8_scales;    // E8M0 scale bytes: A, W of [f8_from, f8_mid) in bits 0-15, A, W of [f8_mid, period) in bits 16-31
-    // LayerNorm tail: after the tiles of a row panel have written the fp32 output, the LAST of them to arrive normalises the panel's rows
-    const float* ln_weight;
-    const float* ln_bias;
-    float ln_eps;
-    op_t* ln_out;
-    long ld_ln;
-    unsigned* ln_counter;
     int bias_row_mod;   // > 0: the bias vector depends on the row: row m uses bias[(m / bias_row_mod) * N + n] (one vector per group of rows)
     FastDiv dBiasMod;
     int a_wrap;      // PLAIN, > 0: the A row is a_wrap elements long and the k-walk wraps around once: K = 2 * a_wrap against [w_hi | w_lo] weights
@@ -264,44 +240,6 @@ ADA_DEV void store_op8(const IgemmDev& p, op_t* dst, int col, float4 v0, float4 
         l[4] = b[0]; l[5] = b[1]; l[6] = b[2]; l[7] = b[3];
         *(opx8*)(dst + p.split_seg) = l;
     }
-}
-
-// LayerNorm folded into the contraction that consumes it (ADA_EP_LNFOLD): the A operand is the UN-normalised row x (operand-typed copy
-// written by the producing epilogue), the weights carry the LayerNorm gain, and with s_n = sum_k W'[n,k], c_n = bias_n + sum_k beta_k W[n,k]
-//     LN(x) W^T + bias  =  rstd * (x W'^T - mean * s) + c
-// so the stand-alone LayerNorm launch (read 4 B + write 2 B per element of the whole token matrix) disappears.
-ADA_DEV float4 ln_fold4(float4 acc, float mu, float rstd, float4 s, float4 c) {
-    float4 v;
-    v.x = (acc.x - mu * s.x) * rstd + c.x; v.y = (acc.y - mu * s.y) * rstd + c.y;
-    v.z = (acc.z - mu * s.z) * rstd + c.z; v.w = (acc.w - mu * s.w) * rstd + c.w;
-    return v;
-}
-// Row statistics for the NEXT LayerNorm, taken from the values this epilogue writes to the fp32 residual stream (ADA_EP_ROWSTATS): the 16
-// lanes that hold one row's 64 columns of a wave tile reduce (sum, sum of squares) with xor shuffles and lane 0 of the group stores
-// the pair -- one slot per (row, 64-column group), no atomics, so the result is bit-reproducible.
-ADA_DEV void rowstat_store(const IgemmDev& p, float4 v, long row, int group, bool leader, bool valid) {
-    float s1 = (v.x + v.y) + (v.z + v.w);
-    float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        s1 += __shfl_xor(s1, o);
-        s2 += __shfl_xor(s2, o);
-    }
-    if (leader && valid) *(float2*)(p.rowstat_out + (row * p.rowstat_groups + group) * 2) = make_float2(s1, s2);
-}
-
-// Sum over the 64 lanes of a wave, result uniform: four DPP row rotations (sum over each 16-lane row in all of its lanes), then the four row
-// sums through SGPRs.  __shfl_xor is ds_bpermute on this part -- an LDS round trip per step, six dependent ones per reduction -- which is what
-// the LayerNorm tail below (two waves per SIMD, nobody to hide the latency behind) cannot afford.
-ADA_DEV float wave_sum_dpp(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
-    const int b = __builtin_bit_cast(int, v);
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
-    return (r0 + r1) + (r2 + r3);
 }
 
 #include "ada_igemm_pipe4.inc"
@@ -776,23 +714,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             const int rsub = lane / CG, cg = CG == 8 ? ((lane - (rsub >> 1)) & 7) : lane % CG;
             const bool relu = (flags & ADA_EP_RELU_OP) != 0;
             const long ld = p.ldo_op;
-            const bool lnfold = EPI != EPI_SHUFFLE && (flags & ADA_EP_LNFOLD) != 0;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int n = nwave + g * GW + 8 * cg;
-                float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, g0 = make_float4(1, 1, 1, 1), g1 = g0, cs0 = b0, cs1 = b0;
+                float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, g0 = make_float4(1, 1, 1, 1), g1 = g0;
                 if (has_bias) { b0 = *(const float4*)(p.bias + n); b1 = *(const float4*)(p.bias + n + 4); }
                 if (has_gamma) { g0 = *(const float4*)(p.gamma + n); g1 = *(const float4*)(p.gamma + n + 4); }
-                if (lnfold) { cs0 = *(const float4*)(p.ln_colsum + n); cs1 = *(const float4*)(p.ln_colsum + n + 4); }
                 op_t* dst = p.out_op + (long)(mbase + rsub) * ld + n;
                 const bool pad = p.map_op == ADA_MAP_PAD;
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
-                    float2 st[32 / RPI];
-                    if (lnfold) {   // (mean, rstd) of this lane's rows, requested before the transpose so they land behind it
-#pragma unroll
-                        for (int k = 0; k < 32 / RPI; ++k) st[k] = *(const float2*)(p.ln_stats + (long)(mbase + i * 32 + k * RPI + rsub) * 2);
-                    }
                     dump(i, g);
                     PadWalk walk;
                     if (pad) walk = pad_start(p, (uint32_t)(mbase + i * 32 + rsub));
@@ -801,13 +732,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                         const int row = k * RPI + rsub;
                         float4 v0 = *(const float4*)(slab + row * SW + 8 * cg);
                         float4 v1 = *(const float4*)(slab + row * SW + 8 * cg + 4);
-                        if (lnfold) {
-                            v0 = ln_fold4(v0, st[k].x, st[k].y, cs0, b0);
-                            v1 = ln_fold4(v1, st[k].x, st[k].y, cs1, b1);
-                        } else {
-                            v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
-                            v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
-                        }
+                        v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
+                        v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
                         if constexpr (EPI == EPI_GELU) {
                             gelu_erf4(v0);
                             gelu_erf4(v1);
@@ -884,15 +810,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                     }
                     v.x = v.x * gamma4.x + rcur[k].x; v.y = v.y * gamma4.y + rcur[k].y;
                     v.z = v.z * gamma4.z + rcur[k].z; v.w = v.w * gamma4.w + rcur[k].w;
-                    if (EPI != EPI_SHUFFLE && (flags & ADA_EP_ROWSTATS)) rowstat_store(p, v, mrow + k * RPI, (nwave + g * GW) >> 6, cg == 0, true);
                     if (p.out_f32) {
                         float4 w = v;
                         if (relu_f) {
                             w.x = __builtin_fmaxf(w.x, 0.f); w.y = __builtin_fmaxf(w.y, 0.f);
                             w.z = __builtin_fmaxf(w.z, 0.f); w.w = __builtin_fmaxf(w.w, 0.f);
                         }
-                        if (p.ln_out || (ADA_EPI_WT && has_res)) st_f32x4_wt(p.out_f32 + (mrow + k * RPI) * ldf + n, w);
-                        else st_f32x4(p.out_f32 + (mrow + k * RPI) * ldf + n, w);
+                        st_f32x4(p.out_f32 + (mrow + k * RPI) * ldf + n, w);
                     }
                     if (p.out_op) {
                         if (relu_o) {
@@ -926,15 +850,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
             const int n = nwave + g * GW + 8 * cg;
             const bool nval = n < p.N;
             const bool nval2 = n + 4 < p.N;
-            float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, g0 = make_float4(1, 1, 1, 1), g1 = g0, cs0 = b0, cs1 = b0;
-            const bool lnfold = EPI != EPI_SHUFFLE && (flags & ADA_EP_LNFOLD) != 0;
+            float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, g0 = make_float4(1, 1, 1, 1), g1 = g0;
             if (flags & ADA_EP_BIAS) {
                 if (nval) b0 = *(const float4*)(p.bias + n);
                 if (nval2) b1 = *(const float4*)(p.bias + n + 4);
-            }
-            if (lnfold) {
-                if (nval) cs0 = *(const float4*)(p.ln_colsum + n);
-                if (nval2) cs1 = *(const float4*)(p.ln_colsum + n + 4);
             }
             if (flags & ADA_EP_GAMMA) {
                 if (nval) g0 = *(const float4*)(p.gamma + n);
@@ -962,14 +881,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                         b0 = nval ? *(const float4*)(brow + n) : make_float4(0, 0, 0, 0);
                         b1 = nval2 ? *(const float4*)(brow + n + 4) : make_float4(0, 0, 0, 0);
                     }
-                    if (lnfold) {
-                        const float2 st = *(const float2*)(p.ln_stats + (long)(m < p.M ? m : p.M - 1) * 2);
-                        v0 = ln_fold4(v0, st.x, st.y, cs0, b0);
-                        v1 = ln_fold4(v1, st.x, st.y, cs1, b1);
-                    } else {
-                        v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
-                        v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
-                    }
+                    v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
+                    v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
                     if constexpr (EPI == EPI_GELU) {
                         gelu_erf4(v0);
                         gelu_erf4(v1);
@@ -1075,7 +988,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                 }
                 v.x = v.x * gamma4.x + rcur[k].x; v.y = v.y * gamma4.y + rcur[k].y;
                 v.z = v.z * gamma4.z + rcur[k].z; v.w = v.w * gamma4.w + rcur[k].w;
-                if (EPI != EPI_SHUFFLE && (flags & ADA_EP_ROWSTATS)) rowstat_store(p, v, (long)m, (nwave + g * GW) >> 6, cg == 0, m < p.M && nval);
                 if (m < p.M && nval) {
                     if (p.out_f32) {
                         const long frow = map_row(p, p.map_f32, (uint32_t)m);
@@ -1084,8 +996,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                             w.x = __builtin_fmaxf(w.x, 0.f); w.y = __builtin_fmaxf(w.y, 0.f);
                             w.z = __builtin_fmaxf(w.z, 0.f); w.w = __builtin_fmaxf(w.w, 0.f);
                         }
-                        if (p.ln_out) st_f32x4_wt(p.out_f32 + frow * p.ldo_f32 + n, w);
-                        else *(float4*)(p.out_f32 + frow * p.ldo_f32 + n) = w;
+                        *(float4*)(p.out_f32 + frow * p.ldo_f32 + n) = w;
                     }
                     if (p.out_op) {
                         if (flags & ADA_EP_RELU_OP) {
@@ -1114,97 +1025,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                     for (int k = 0; k < NKI; ++k) rcur[k] = rnext[k];
                 }
             }
-        }
-    }
-    // ---- LayerNorm tail (ada_igemm_args.ln_out): the LayerNorm that follows proj / fc2 (reference block.py:84,87) reads exactly the rows this
-    //      launch has just written to the fp32 residual stream.  Every tile publishes its part of the row panel (write-through stores above, the
-    //      wave's stores drained, one ticket per tile on the panel's counter); the tile that draws the last ticket normalises the panel's rows
-    //      from memory and writes the operand-typed LayerNorm output -- no separate launch, no second pass of all CUs over the stream.
-    //      Protocol: cdna_hip_programming.md section 6 Guideline 16 (R1: sc1 stores, vmcnt(0), __syncthreads(), relaxed agent-scope fetch_add;
-    //      reader: sc1 loads) -- correct for any placement of a panel's tiles over CUs / XCDs.  The result does not depend on which tile is last.
-    //      Built into the 256x256 tile's standard-epilogue kernel only (the tail keeps 8 rows x 6 chunks per lane in flight: 192 registers, which the
-    //      co-resident small tiles cannot spare); ada_igemm pins that tile when ln_out is set.
-    constexpr bool HAS_LN_TAIL = BM == 256 && BN == 256 && NWAVES == 8 && EPI == EPI_STD && !PIPE4;
-    if (HAS_LN_TAIL && p.ln_out) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through stores have reached memory
-        __syncthreads();
-        unsigned* const ticket = (unsigned*)smem;            // the stage buffers / epilogue slabs are dead
-        if (tid == 0) *ticket = __hip_atomic_fetch_add(p.ln_counter + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const unsigned drawn = *(volatile unsigned*)ticket;
-        if (drawn == (unsigned)p.tiles_n - 1u) {
-            if (tid == 0) __hip_atomic_store(p.ln_counter + tm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-#if ADA_LN_TAIL_PLAIN
-            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // experiment: acquire + plain loads instead of sc1 loads
-            __syncthreads();
-#endif
-            const int nchunk = p.N >> 2;                     // float4 chunks per row (N % 4 == 0; N <= 1536)
-            const int rows = (p.M - m0) < BM ? (p.M - m0) : BM;
-            // a buffer resource over the panel: sc1 loads (L1 bypassed; nobody on this XCD has read these lines during the launch) with compiler-managed waits
-            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_f32 + (long)m0 * p.ldo_f32), 0, 0x7fffffff, 0x20000);
-            const float inv_n = 1.0f / (float)p.N;
-            // A wave owns BM / NWAVES consecutive rows and takes them RB at a time: all loads of a batch are in flight together, the LayerNorm gain /
-            // bias of the lane's columns stay in registers, the reductions run on DPP.  (Row by row with shuffle reductions the panel took ~140 us --
-            // 32 dependent memory round trips and ~400 LDS round trips per wave with one partner wave to hide them behind; profiles/r04_j_*.)
-            constexpr int RPW = BM / NWAVES;
-            auto ln_rows = [&](auto ch_, auto rb_) {
-                constexpr int CH = decltype(ch_)::value, RB = decltype(rb_)::value;
-                static_assert(RPW % RB == 0, "rows per wave vs batch");
-                float4 gw[CH], gb[CH];
-#pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    const int c = lane + 64 * i;
-                    gw[i] = gb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (c < nchunk) { gw[i] = *(const float4*)(p.ln_weight + 4 * c); gb[i] = *(const float4*)(p.ln_bias + 4 * c); }
-                }
-                for (int r0 = wave * RPW; r0 < wave * RPW + RPW && r0 < rows; r0 += RB) {
-                    f32x4 v[RB][CH];
-#pragma unroll
-                    for (int j = 0; j < RB; ++j) {
-                        const int r = r0 + j < rows ? r0 + j : rows - 1;
-#pragma unroll
-                        for (int i = 0; i < CH; ++i) {
-                            const int c = lane + 64 * i;
-                            v[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            if (c < nchunk)
-                                v[j][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(((long)r * p.ldo_f32 + 4 * c) * 4), 0, ADA_LN_TAIL_PLAIN ? 0 : 16));
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < RB; ++j) {
-                        float s1 = 0.0f;
-#pragma unroll
-                        for (int i = 0; i < CH; ++i) s1 += (v[j][i][0] + v[j][i][1]) + (v[j][i][2] + v[j][i][3]);     // chunks past the row are zero
-                        const float mean = wave_sum_dpp(s1) * inv_n;
-                        float s2 = 0.0f;
-#pragma unroll
-                        for (int i = 0; i < CH; ++i) {
-                            if (lane + 64 * i < nchunk) {
-                                const float a = v[j][i][0] - mean, b = v[j][i][1] - mean, c2 = v[j][i][2] - mean, d = v[j][i][3] - mean;
-                                s2 += (a * a + b * b) + (c2 * c2 + d * d);
-                            }
-                        }
-                        const float rstd = 1.0f / sqrtf(wave_sum_dpp(s2) * inv_n + p.ln_eps);
-                        if (r0 + j < rows) {
-                            op_t* const yrow = p.ln_out + (long)(m0 + r0 + j) * p.ld_ln;
-#pragma unroll
-                            for (int i = 0; i < CH; ++i) {
-                                const int c = lane + 64 * i;
-                                if (c < nchunk) {
-                                    float4 y;
-                                    y.x = (v[j][i][0] - mean) * rstd * gw[i].x + gb[i].x;
-                                    y.y = (v[j][i][1] - mean) * rstd * gw[i].y + gb[i].y;
-                                    y.z = (v[j][i][2] - mean) * rstd * gw[i].z + gb[i].z;
-                                    y.w = (v[j][i][3] - mean) * rstd * gw[i].w + gb[i].w;
-                                    *(opx4*)(yrow + 4 * c) = pack4(y);
-                                }
-                            }
-                        }
-                    }
-                }
-            };
-            if (nchunk <= 256) ln_rows(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});     // N <= 1024
-            else ln_rows(std::integral_constant<int, 6>{}, std::integral_constant<int, 4>{});                   // N <= 1536
         }
     }
     if (!PIPE4 && p.dbg && tid == 0) {
@@ -1286,14 +1106,14 @@ static inline double tile_time_cu(long M, long N, long K, int bm, int bn, double
 // 4-wave loop where its main loop outweighs its slower prologue / epilogue (measured: k-loops of >= 128 k-tiles)
 // (its scalar A-offset counters assume a monotonic walk: a split operand, whose third k segment re-reads the first, stays on the 8-wave loop)
 static inline bool use_pipe4(const IgemmDev& d) {
-    if (d.a_dup_seg != 0 || d.a_wrap != 0 || d.f8_from != 0 || d.tap_cols != 0 || d.ln_out != nullptr) return false;
+    if (d.a_dup_seg != 0 || d.a_wrap != 0 || d.f8_from != 0 || d.tap_cols != 0) return false;
     if (d.variant != 0) return d.variant >= 16;
     if (d.K >= 8192) return true;
     // With a cheap operand-typed epilogue (bias, SwiGLU: no fp32 output, no residual / LayerScale / GELU / row statistics) the slower epilogue of the
     // one-wave-per-SIMD loop weighs less and it wins from 24 k-steps on launches of many rounds: raw ViT-G at 8 x 1022^2, w12 (N = 8192, K = 1536)
     // 966 -> 909 us, qkv 526 -> 515 (profiles/r05_j_config5_shapes.txt).  At K = 1024 (ViT-L: qkv -3 %, fc1 + GELU -7 %) it still loses.
     const bool cheap = d.a_mode == ADA_A_PLAIN && d.out_f32 == nullptr && d.bias_row_mod == 0 &&
-                       !(d.flags & (ADA_EP_RESIDUAL | ADA_EP_GAMMA | ADA_EP_GELU | ADA_EP_ROWSTATS | ADA_EP_LNFOLD | ADA_EP_RELU_OP));
+                       !(d.flags & (ADA_EP_RESIDUAL | ADA_EP_GAMMA | ADA_EP_GELU | ADA_EP_RELU_OP));
     return cheap && d.K >= 1536 && (long)((d.M + 255) / 256) * ((d.N + 255) / 256) >= 2048;
 }
 
@@ -1327,9 +1147,6 @@ int launch_epi(IgemmDev& d, hipStream_t s, int force) {
     }
     if (d.M < 256 && cfg >= 2 && cfg != 4) cfg = 4;
     if (force >= 0 && force <= 4) cfg = force;
-    if (d.ln_out) cfg = 3;     // the LayerNorm tail lives in the 256x256 tile's kernel
-    // EP_ROWSTATS reduces a row over the 16 lanes that hold one 64-column group: the 32-column-wide 256x32 tile has no such group
-    if ((d.flags & ADA_EP_ROWSTATS) && cfg == 0) cfg = 1;
     if constexpr (EPI == EPI_SWIGLU) {
         if (cfg == 4 || cfg == 2) return launch_cfg<128, 128, 64, 2, 2, EPI>(d, s);
         if (use_pipe4(d)) return launch_cfg<256, 256, 64, 2, 2, EPI, 2>(d, s);
@@ -1435,35 +1252,18 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
                     "ada_igemm: SHUFFLE needs N == s*s*c");
         ADA_REQUIRE(a->shuffle_c % 4 == 0 && !a->out_f32 && !(f & ADA_EP_GELU), ADA_EUNSUPPORTED, "ada_igemm: SHUFFLE needs c %% 4 == 0, operand output only");
     }
-    if (f & ADA_EP_LNFOLD) {
-        ADA_REQUIRE(a->ln_stats && a->ln_colsum && a->bias && (f & ADA_EP_BIAS), ADA_EINVAL, "ada_igemm: EP_LNFOLD needs ln_stats, ln_colsum and bias (the folded constant)");
-        ADA_REQUIRE(a->out_op && !a->out_f32 && !(f & (ADA_EP_RESIDUAL | ADA_EP_GAMMA)) && !tail && !swiglu && !shuffle && a->a_mode == ADA_A_PLAIN &&
-                    a->map_op == ADA_MAP_PLAIN && a->N % 8 == 0 && a->ldo_op % 8 == 0, ADA_EUNSUPPORTED,
-                    "ada_igemm: EP_LNFOLD supports plain linear layers with an operand-typed output (bias / GELU epilogues), N %% 8 == 0");
-        ADA_REQUIRE(((uintptr_t)a->ln_stats % 8) == 0 && ((uintptr_t)a->ln_colsum % 16) == 0, ADA_EINVAL, "ada_igemm: ln_stats / ln_colsum alignment");
-    }
-    if (f & ADA_EP_ROWSTATS) {
-        ADA_REQUIRE(a->rowstat_out && a->N % 64 == 0 && a->N >= 64 && !tail && !swiglu && !shuffle, ADA_EINVAL, "ada_igemm: EP_ROWSTATS needs rowstat_out and N %% 64 == 0");
-        ADA_REQUIRE((a->out_f32 || (f & ADA_EP_RESIDUAL)) && (!a->out_f32 || a->map_f32 == ADA_MAP_PLAIN) && a->res_row_mod == 0, ADA_EUNSUPPORTED,
-                    "ada_igemm: EP_ROWSTATS is implemented for the fp32 / residual epilogue with a plain row map");
-        ADA_REQUIRE(((uintptr_t)a->rowstat_out % 8) == 0, ADA_EINVAL, "ada_igemm: rowstat_out must be 8-byte aligned");
-    }
     const int split_abs = a->split_seg < 0 ? -a->split_seg : a->split_seg;   // < 0: the [hi | lo8 | hi8] form
     if (a->split_seg != 0) {
         ADA_REQUIRE(a->out_op && split_abs % 8 == 0 && !swiglu, ADA_EINVAL, "ada_igemm: split_seg needs out_op, a multiple of 8, no SwiGLU");
-        ADA_REQUIRE(a->split_seg > 0 || !shuffle || a->shuffle_c % 8 == 0, ADA_EUNSUPPORTED, "ada_igemm: the fp8 form of a split output (split_seg < 0) behind MAP_SHUFFLE needs shuffle_c %% 8 == 0");
+        // (behind a shuffle only the 8-column operand-only epilogue writes the [hi | lo8 | hi8] form: its conditions are required here, or the 4-column
+        //  path -- compiled without the fp8 form for EPI_SHUFFLE -- would write [hi | lo] where the consumer reads bytes)
+        ADA_REQUIRE(a->split_seg > 0 || !shuffle || (a->shuffle_c % 8 == 0 && !(f & ADA_EP_RESIDUAL) && a->ldo_op % 8 == 0), ADA_EUNSUPPORTED,
+                    "ada_igemm: the fp8 form of a split output (split_seg < 0) behind MAP_SHUFFLE needs shuffle_c %% 8 == 0, ldo_op %% 8 == 0 and no residual");
         const int cols = shuffle ? a->shuffle_c : a->N;
         ADA_REQUIRE(cols <= split_abs && a->ldo_op >= 2L * split_abs, ADA_EINVAL, "ada_igemm: split_seg=%d too small for %d columns / ldo_op=%ld", a->split_seg, cols, (long)a->ldo_op);
     }
-    if (a->ln_out) {
-        ADA_REQUIRE(a->ln_weight && a->ln_bias && a->ln_counter && a->out_f32 && a->map_f32 == ADA_MAP_PLAIN && a->res_row_mod == 0 && !tail && !swiglu && !shuffle &&
-                    a->N <= 1536 && a->N % 4 == 0 && a->ldo_f32 % 4 == 0 && a->ld_ln % 4 == 0 && ((uintptr_t)a->ln_out % 8) == 0 &&
-                    ((uintptr_t)a->ln_weight % 16) == 0 && ((uintptr_t)a->ln_bias % 16) == 0, ADA_EUNSUPPORTED,
-                    "ada_igemm: the LayerNorm tail needs a plain fp32 output whose N (<= 1536) is the whole LayerNorm row, ln_weight / ln_bias / ln_counter, 8-byte aligned ln_out");
-        ADA_REQUIRE(!(f & (ADA_EP_GELU | ADA_EP_ROWSTATS | ADA_EP_LNFOLD)), ADA_EUNSUPPORTED, "ada_igemm: the LayerNorm tail is built for the standard (bias / LayerScale / residual) epilogue");
-    }
     if (a->bias_row_mod != 0) {
-        ADA_REQUIRE(a->bias_row_mod > 0 && (f & ADA_EP_BIAS) && a->out_op && !a->out_f32 && !(f & (ADA_EP_RESIDUAL | ADA_EP_LNFOLD)) && !tail && !swiglu && !shuffle &&
+        ADA_REQUIRE(a->bias_row_mod > 0 && (f & ADA_EP_BIAS) && a->out_op && !a->out_f32 && !(f & ADA_EP_RESIDUAL) && !tail && !swiglu && !shuffle &&
                     a->ldo_op % 8 == 0 && a->N % 4 == 0, ADA_EUNSUPPORTED,
                     "ada_igemm: bias_row_mod (a bias vector per group of rows) is implemented for operand-typed outputs with ldo_op %% 8 == 0 (bias / GELU epilogues)");
     }
@@ -1473,7 +1273,7 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     }
     if (a->f8_from != 0) {
         const long per = a->a_mode == ADA_A_CONV3 ? a->lda : (long)a->K;     // period of the k-walk in operand slots
-        ADA_REQUIRE(a->a_dup_seg == 0 && a->a_wrap == 0 && !(f & ADA_EP_LNFOLD), ADA_EINVAL, "ada_igemm: f8_from excludes a_dup_seg / a_wrap / EP_LNFOLD");
+        ADA_REQUIRE(a->a_dup_seg == 0 && a->a_wrap == 0, ADA_EINVAL, "ada_igemm: f8_from excludes a_dup_seg / a_wrap");
         ADA_REQUIRE(a->f8_from > 0 && a->f8_from % 64 == 0 && a->f8_mid % 64 == 0 && a->f8_from <= a->f8_mid && a->f8_mid <= per && a->f8_from < per, ADA_EINVAL,
                     "ada_igemm: f8_from=%d / f8_mid=%d must be multiples of 64 with 0 < f8_from <= f8_mid <= %ld (the period of the k-walk)", a->f8_from, a->f8_mid, per);
     }
@@ -1511,16 +1311,12 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     d.f8_from = a->f8_from / 64; d.f8_mid = a->f8_mid / 64; d.f8_scales = a->f8_scales;
     d.a_dup_seg = a->a_dup_seg;
     d.a_wrap = a->a_wrap;
-    d.ln_weight = a->ln_weight; d.ln_bias = a->ln_bias; d.ln_eps = a->ln_eps; d.ln_out = (op_t*)a->ln_out; d.ld_ln = a->ld_ln;
-    d.ln_counter = (unsigned*)a->ln_counter;
     d.bias_row_mod = a->bias_row_mod;
     d.dBiasMod = make_fastdiv(a->bias_row_mod > 0 ? a->bias_row_mod : 1);
     d.tap_cols = a->tap_cols;
     d.tap_bits[0] = d.tap_bits[1] = d.tap_bits[2] = 0;
     if (a->tap_cols > 0)
         for (int i = 0; i < a->N / a->tap_cols; ++i) d.tap_bits[i / 7] |= (unsigned long long)a->tap_mask[i] << (9 * (i % 7));
-    d.ln_stats = a->ln_stats; d.ln_colsum = a->ln_colsum;
-    d.rowstat_out = a->rowstat_out; d.rowstat_groups = a->N / 64;
     d.dShC = make_fastdiv(a->shuffle_c > 0 ? a->shuffle_c : 1);
     d.dShS = make_fastdiv(a->shuffle_s > 0 ? a->shuffle_s : 1);
     d.tail_w = a->tail_w; d.tail_b = a->tail_b; d.tail_act = a->tail_act;

@@ -18,17 +18,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
 # --- constants mirrored from include/ada_hip.h ------------------------------------------------
-ABI_VERSION = 7
+ABI_VERSION = 8
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 A_PLAIN, A_CONV3 = 0, 1
 MAP_PLAIN, MAP_PAD, MAP_TOKEN, MAP_SHUFFLE = 0, 1, 2, 3
 EP_BIAS, EP_GELU, EP_GAMMA, EP_RESIDUAL, EP_RELU_OP, EP_SWIGLU, EP_TAIL, EP_RELU_F32 = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40, 0x80
-EP_ROWSTATS, EP_LNFOLD = 0x100, 0x200
 ACT_NONE, ACT_SIGMOID, ACT_RELU = 0, 1, 2
 
 EXPORTS = (
     "ada_abi_version", "ada_operand_dtype", "ada_last_error", "ada_igemm", "ada_attention_fwd",
-    "ada_rowstats_finalize", "ada_pos_embed_resize", "ada_layernorm_fwd", "ada_layernorm_ex", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
+    "ada_pos_embed_resize", "ada_layernorm_fwd", "ada_layernorm_ex", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
     "ada_minmax_fwd", "ada_depth_stats_fwd", "ada_token_diversity_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd", "ada_dpt_tail_fwd", "ada_tapsum_resize_fwd",
     "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
     "ada_debug_set_timestamps", "ada_debug_set_attention_variant", "ada_debug_count_saturated",
@@ -52,9 +51,8 @@ class IgemmArgs(ctypes.Structure):
         ("out_op", c_void_p), ("ldo_op", c_int64), ("map_op", c_int32),
         ("map_h", c_int32), ("map_w", c_int32), ("shuffle_s", c_int32), ("shuffle_c", c_int32),
         ("tail_w", c_void_p), ("tail_b", c_float), ("tail_act", c_int32),
-        ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("rowstat_out", c_void_p), ("split_seg", c_int32), ("a_dup_seg", c_int32),
+        ("split_seg", c_int32), ("a_dup_seg", c_int32),
         ("tap_cols", c_int32), ("tap_mask", c_uint16 * 16), ("a_wrap", c_int32), ("bias_row_mod", c_int32),
-        ("ln_weight", c_void_p), ("ln_bias", c_void_p), ("ln_eps", c_float), ("ln_out", c_void_p), ("ld_ln", c_int64), ("ln_counter", c_void_p),
         ("f8_from", c_int32), ("f8_mid", c_int32), ("f8_scales", ctypes.c_uint32),
     ]
 
@@ -107,8 +105,6 @@ def load(path: Optional[str] = None):
     lib.ada_igemm.restype = c_int
     lib.ada_pos_embed_resize.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_int32, c_double, c_double, c_void_p, c_void_p]
     lib.ada_pos_embed_resize.restype = c_int
-    lib.ada_rowstats_finalize.argtypes = [c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p]
-    lib.ada_rowstats_finalize.restype = c_int
     lib.ada_attention_fwd.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]
     lib.ada_attention_fwd.restype = c_int
     lib.ada_layernorm_fwd.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_float,
@@ -229,7 +225,7 @@ def set_timer(t: Optional[KernelTimer]):
 def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=None, gamma=None, res=None, ldr=0,
           res_row_mod=0, res_row_off=0, flags=0, out_f32=None, ldo_f32=0, map_f32=MAP_PLAIN, out_op=None, ldo_op=0,
           map_op=MAP_PLAIN, map_h=0, map_w=0, shuffle_s=0, shuffle_c=0, tail_w=None, tail_b=0.0, tail_act=ACT_NONE, split_seg=0,
-          ln_stats=None, ln_colsum=None, rowstat_out=None, a_dup_seg=0, tap_cols=0, tap_mask=None, a_wrap=0, bias_row_mod=0, ln_weight=None, ln_bias=None, ln_eps=0.0, ln_out=None, ld_ln=0, ln_counter=None,
+          a_dup_seg=0, tap_cols=0, tap_mask=None, a_wrap=0, bias_row_mod=0,
           f8_from=0, f8_mid=0, f8_scales=0):
     op = operand_dtype()
     a = IgemmArgs()
@@ -251,15 +247,10 @@ def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=Non
     a.a_wrap = a_wrap
     a.bias_row_mod = bias_row_mod
     a.f8_from, a.f8_mid, a.f8_scales = f8_from, f8_mid, f8_scales
-    if ln_out is not None:
-        a.ln_weight, a.ln_bias, a.ln_eps = _dev(ln_weight, "ln_weight", torch.float32), _dev(ln_bias, "ln_bias", torch.float32), ln_eps
-        a.ln_out, a.ld_ln, a.ln_counter = _dev(ln_out, "ln_out", op), ld_ln, _dev(ln_counter, "ln_counter", torch.int32)
     if tap_cols:
         a.tap_cols = tap_cols
         for i, m in enumerate(tap_mask):
             a.tap_mask[i] = int(m)
-    a.ln_stats, a.ln_colsum = _opt(ln_stats, "ln_stats", torch.float32), _opt(ln_colsum, "ln_colsum", torch.float32)
-    a.rowstat_out = _opt(rowstat_out, "rowstat_out", torch.float32)
     if _timer is not None and _timer.active:
         ev = _timer.start()
         _check(load().ada_igemm(ctypes.byref(a), _stream()), "ada_igemm")
@@ -268,12 +259,6 @@ def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=Non
         _check(load().ada_igemm(ctypes.byref(a), _stream()), "ada_igemm")
     if _tile_log is not None:
         _tile_log.append((M, N, K, load().ada_debug_last_tile()))
-
-
-def rowstats_finalize(partials: torch.Tensor, rows: int, groups: int, eps: float, stats: torch.Tensor):
-    """partials fp32 [rows, groups, 2] -> stats fp32 [rows, 2] = (mean, rstd) (ada_rowstats_finalize)."""
-    _check(load().ada_rowstats_finalize(_dev(partials, "partials", torch.float32), rows, groups, eps, _dev(stats, "stats", torch.float32), _stream()),
-           "ada_rowstats_finalize")
 
 
 def attention(qkv: torch.Tensor, out: torch.Tensor, batch: int, n_tokens: int, heads: int):

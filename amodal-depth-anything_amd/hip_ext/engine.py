@@ -26,8 +26,8 @@ from typing import Dict, Optional
 import torch
 import torch.nn.functional as F
 
-from . import (A_CONV3, ACT_NONE, ACT_RELU, ACT_SIGMOID, EP_BIAS, EP_GAMMA, EP_GELU, EP_LNFOLD, EP_RELU_OP, EP_RESIDUAL,
-               EP_ROWSTATS, EP_SWIGLU, EP_TAIL, MAP_PAD, MAP_SHUFFLE, MAP_TOKEN, HipExtError)
+from . import (A_CONV3, ACT_NONE, ACT_RELU, ACT_SIGMOID, EP_BIAS, EP_GAMMA, EP_GELU, EP_RELU_OP, EP_RESIDUAL,
+               EP_SWIGLU, EP_TAIL, MAP_PAD, MAP_SHUFFLE, MAP_TOKEN, HipExtError)
 from . import attention as k_attention
 from . import bilinear as _bilinear
 from . import count_saturated
@@ -39,7 +39,6 @@ from . import depth_stats as k_depth_stats
 from . import token_diversity as k_token_diversity
 from . import patchify as k_patchify
 from . import pos_embed_resize as k_pos_embed_resize
-from . import rowstats_finalize as k_rowstats_finalize
 from . import tapsum_resize as k_tapsum_resize
 from . import write_cls as k_write_cls
 
@@ -88,12 +87,8 @@ SUBPIXEL = os.environ.get("ADA_SUBPIXEL", "1") == "1"
 # -- ONE GEMM over the 148^2 grid with N = 9 * features / 2 (0.41 TFLOP at ViT-L bs = 32 instead of out_conv 0.09 + output_conv1 1.65) whose nine
 # operand-typed tap maps ada_tapsum_resize_fwd gathers (9 taps x 4 bilinear corners per output element; a tap whose position falls into the
 # zero padding drops out whole, out_conv's bias included).  The up-sampled operand map p1 is never written.  ADA_OC1_COMMUTE=0: the old path.
-# LayerNorm tail (round 4, ada_igemm_args.ln_out): norm2 behind attn.proj and the next block's norm1 behind mlp.fc2 (block.py:84,87) are computed by
-# the proj / fc2 launch itself -- the last-arriving tile of every 256-row panel normalises the panel it has just completed -- instead of by a
-# separate pass of all CUs over the fp32 residual stream.  ADA_LN_TAIL=0: separate ada_layernorm launches.
-LN_TAIL = os.environ.get("ADA_LN_TAIL", "0") == "1"
 STAT_CHUNKS = 8
-OC1_COMMUTE = int(os.environ.get("ADA_OC1_COMMUTE", "16"))     # 0: off; 16: operand-typed tap maps (default); 32: fp32 tap maps (no parity gain, slower)
+OC1_COMMUTE = os.environ.get("ADA_OC1_COMMUTE", "1") != "0"     # operand-typed tap maps; 0: the resize -> conv path (A/B, profiles/r04_g_*; also the path of a split-precision oc1)
 
 
 # fp8 correction terms (ada_igemm_args.f8_from): a split-precision product whose two small terms x_lo w_hi + x_hi w_lo run on the fp8 matrix pipe
@@ -163,7 +158,7 @@ class PackedWeights:
     with the *raw* model's key names (``pretrained.*``, ``depth_head.*``)."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], encoder: str, guided: bool, amodal_head: bool, split_head=False,
-                 fold_ln: bool = False, enc_split_blocks: int = 0, head_only: bool = False, tap_split: bool = False,
+                 enc_split_blocks: int = 0, head_only: bool = False, tap_split: bool = False,
                  f8: str = "both", tap_f8: Optional[bool] = None, f8_only=None):
         op = operand_dtype()
         # head_only: the DPT head's weights only (the second rung of the precision ladder, DepthEngine._escalate, re-runs the head from the taps)
@@ -185,18 +180,13 @@ class PackedWeights:
         if unknown:
             raise HipExtError(f"unknown head layer group(s) {sorted(unknown)}; known: {HEAD_GROUPS}")
         self.split_head = bool(self.split)
-        # fold_ln: the block LayerNorms (reference block.py:84,87) are folded into the qkv / fc1 contractions that consume them --
-        # gain into the weights, mean / rstd applied in the GEMM epilogue (ADA_EP_LNFOLD), row statistics produced by the proj / fc2
-        # epilogue that writes the residual stream (ADA_EP_ROWSTATS): no stand-alone LayerNorm launch between the GEMMs of a block
-        # (only the very first LayerNorm of the encoder, whose input comes from the patch embedding, runs as a kernel).  MLP blocks only.
-        self.fold_ln = bool(fold_ln) and cfg["ffn"] == "mlp"
         # enc_split_blocks = K: the linear layers of the FIRST K transformer blocks run in split precision.  Operand rounding noise injected
         # early is amplified by every later block (oracle study, profiles/r04_e_raw_vitg_operand_noise_by_block.txt: blocks 0-9 of ViT-G carry
         # half of the encoder's share, blocks 30-39 a fiftieth), so for the unbounded-output ViT-G model, whose encoder alone reaches
         # 0.7e-3 ... 1.05e-3 depending on the weight draw, the head's split precision is not enough.  qkv and fc1 / w12 read the LayerNorm
         # output as [hi | lo] (full three-term product); proj and fc2 / w3 read activations that exist in the operand type only (attention
         # output, MLP hidden) against [w_hi | w_lo] weights (ada_igemm_args.a_wrap: the weight's rounding error goes, the activation's stays).
-        self.enc_split_blocks = 0 if self.fold_ln else max(0, min(int(enc_split_blocks), cfg["depth"]))
+        self.enc_split_blocks = max(0, min(int(enc_split_blocks), cfg["depth"]))
         # ... with the two correction terms of qkv / fc1 / w12 on the fp8 matrix pipe where the build has it (fp16 operands, D a multiple of 128)
         # f8: which of the two users take it -- "both" | "enc" | "head" | "none" (the caller's precision policy, DA2/dpt.py::_f8_policy)
         if f8 not in ("both", "enc", "head", "none"):
@@ -299,14 +289,6 @@ class PackedWeights:
                 blk.update(fc1_w=fc1_w, fc1_f8=fc1_f8, fc1_b=f32(b + "mlp.fc1.bias"),
                            fc2_w=lin2(f32(b + "mlp.fc2.weight")), fc2_b=f32(b + "mlp.fc2.bias"))
                 blk["hidden"] = blk["fc1_w"].shape[0]
-                if self.fold_ln:
-                    def fold(wmat, bias, g, beta):   # LN(x) W^T + b = rstd (x W'^T - mean s) + c
-                        wf = lin(wmat * g[None, :])
-                        return wf, wf.float().sum(1).contiguous(), (bias + wmat @ beta).contiguous()
-                    fw = f32(b + "mlp.fc1.weight")
-                    blk["fc1_wf"], blk["fc1_s"], blk["fc1_c"] = fold(fw, blk["fc1_b"], blk["ln2_w"], blk["ln2_b"])
-                    if i > 0:   # block 0's first LayerNorm reads the patch-embedding output: it stays a kernel
-                        blk["qkv_wf"], blk["qkv_s"], blk["qkv_c"] = fold(qw, qb, blk["ln1_w"], blk["ln1_b"])
             else:
                 w12, b12 = f32(b + "mlp.w12.weight"), f32(b + "mlp.w12.bias")
                 hid = w12.shape[0] // 2
@@ -503,13 +485,8 @@ class Workspace:
         if not head_only:
             self.a_pe = z(P, 2 * pw_.pe_seg)     # split-precision patches: [hi | lo]
             self.x = z(T, D, dtype=torch.float32)
-            # LayerNorm output ([hi | lo] column segments for the split-precision blocks: PackedWeights.enc_split_blocks); with folded LayerNorms: the
-            # operand-typed copy of the residual stream itself
+            # LayerNorm output ([hi | lo] column segments for the split-precision blocks: PackedWeights.enc_split_blocks)
             self.y = z(T, 2 * D if pw_.enc_split_blocks > 0 else D)
-            if pw_.fold_ln:
-                self.part = z(T, D // 64, 2, dtype=torch.float32)    # per-row partial (sum, sum of squares), one slot per 64 columns
-                self.stats = z(T, 2, dtype=torch.float32)            # (mean, rstd) per row
-            self.ln_cnt = torch.zeros(T // 128 + 2, dtype=torch.int32, device=device)     # per-row-panel tickets of the LayerNorm tail (kernel-reset)
             self.qkv = z(T, 3 * D)
             self.o = z(T, D)
             hidden = pw_.blocks[0]["hidden"]
@@ -571,7 +548,7 @@ class Workspace:
         self.g296 = (2 * g0[0], 2 * g0[1])
         self.p1 = None if pw_.oc1c is not None else z(B, self.g296[0] + 2, self.g296[1] + 2, mm("oc1") * Fp)
         # the nine tap maps of output_conv1 on the level-0 grid
-        self.tmaps = z(rows[0], 9 * (Fch // 2), dtype=torch.float32 if OC1_COMMUTE == 32 else op) if pw_.oc1c is not None else None
+        self.tmaps = z(rows[0], 9 * (Fch // 2)) if pw_.oc1c is not None else None
         half = Fch // 2
         self.half, self.halfp = half, _r64(half)
         self.oc1 = lvl0.view(B * self.g296[0] * self.g296[1], half)
@@ -649,6 +626,7 @@ class DepthEngine:
             raise HipExtError("precision ladder: the engine's weights must be packed with tap_split=True")
         self._w_hi: Optional[PackedWeights] = None
         self._ws_hi: "OrderedDict[tuple, Workspace]" = OrderedDict()
+        self.block_probe = None       # diagnostic hook: callable(block index, workspace) behind every transformer block (never set on the product path)
         self._eng3: Optional["DepthEngine"] = None       # third rung: an engine with every encoder block and the whole head in split precision
         self.escalated = 0            # images the ladder has re-run so far (second + third rung)
         self.escalated3 = 0           # ... of which on the third rung
@@ -747,7 +725,7 @@ class DepthEngine:
         if not use or instrumented() or torch.cuda.is_current_stream_capturing():
             return self._escalate(None, self._forward(x, guide, norm), x, guide, norm)
         # the kernel variant / tile override / fused-tail switch in force at capture time are baked into the graph
-        key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device), debug_epoch(), FUSED_TAIL, SUBPIXEL, OC1_COMMUTE, LN_TAIL, norm)
+        key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device), debug_epoch(), FUSED_TAIL, SUBPIXEL, OC1_COMMUTE, norm)
         with self._lock:
             g = self._graphs.get(key)
             if g is not None:
@@ -900,8 +878,6 @@ class DepthEngine:
 
         # ---- transformer blocks ------------------------------------------------------------------
         taps = TAPS[w.encoder]
-        fold = w.fold_ln
-        G = D // 64
         ldy = ws.y.shape[1]
 
         def a_ln(blk_, wname):      # A-operand arguments of a linear layer that reads the LayerNorm output ws.y: plain, or [hi | lo] / [hi | lo8 | hi8] in a split block
@@ -916,61 +892,35 @@ class DepthEngine:
 
         def seg(blk_):              # split_seg of the LayerNorm that feeds blk_'s linear layers
             return (-D if w.enc_f8 else D) if blk_["esplit"] else 0
-        def lntail(blk_, wk, bk):   # LayerNorm-tail arguments of a proj / fc2 launch whose output rows feed LayerNorm (blk_[wk], blk_[bk]) -> ws.y
-            # (the tail lives in the 256x256 tile's kernel: only where the tile heuristic takes that tile anyway -- at least a full round of tiles)
-            if not LN_TAIL or blk_["esplit"] or D > 1536 or T < 16384:
-                return {}
-            return dict(ln_weight=blk_[wk], ln_bias=blk_[bk], ln_eps=LN_EPS, ln_out=ws.y, ld_ln=ldy, ln_counter=ws.ln_cnt)
         ln1_done = False    # block i's norm1 output already sits in ws.y (emitted by the tap LayerNorm of block i - 1, see below)
         for i, blk in enumerate(w.blocks):
             last = i == len(w.blocks) - 1
             if ln1_done:
                 ln1_done = False
                 k_igemm(M=T, N=3 * D, k_alg=D, A=ws.y, W=blk["qkv_w"], bias=blk["qkv_b"], flags=EP_BIAS, out_op=ws.qkv, ldo_op=3 * D, **a_ln(blk, "qkv_w"))
-            elif fold and i > 0:   # x arrives as the operand-typed copy written by the previous fc2 epilogue, with its row statistics
-                k_igemm(M=T, N=3 * D, K=D, A=ws.y, lda=D, W=blk["qkv_wf"], bias=blk["qkv_c"], ln_stats=ws.stats, ln_colsum=blk["qkv_s"],
-                        flags=EP_BIAS | EP_LNFOLD, out_op=ws.qkv, ldo_op=3 * D)
             else:
                 k_layernorm(ws.x, D, T, D, blk["ln1_w"], blk["ln1_b"], LN_EPS, out_op=ws.y, ld_op=ldy, split_seg=seg(blk))
                 k_igemm(M=T, N=3 * D, k_alg=D, A=ws.y, W=blk["qkv_w"], bias=blk["qkv_b"], flags=EP_BIAS, out_op=ws.qkv, ldo_op=3 * D, **a_ln(blk, "qkv_w"))
             k_attention(ws.qkv, ws.o, B, N, heads)
             hid = blk["hidden"]
-            if fold:
-                k_igemm(M=T, N=D, K=D, A=ws.o, lda=D, W=blk["proj_w"], bias=blk["proj_b"], gamma=blk["ls1"], res=ws.x, ldr=D,
-                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL | EP_ROWSTATS, out_f32=ws.x, ldo_f32=D, out_op=ws.y, ldo_op=D, rowstat_out=ws.part)
-                k_rowstats_finalize(ws.part, T, G, LN_EPS, ws.stats)
-                k_igemm(M=T, N=hid, K=D, A=ws.y, lda=D, W=blk["fc1_wf"], bias=blk["fc1_c"], ln_stats=ws.stats, ln_colsum=blk["fc1_s"],
-                        flags=EP_BIAS | EP_GELU | EP_LNFOLD, out_op=ws.hd, ldo_op=hid)
-                if last:
-                    k_igemm(M=T, N=D, K=hid, A=ws.hd, lda=hid, W=blk["fc2_w"], bias=blk["fc2_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
-                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D)
-                else:
-                    k_igemm(M=T, N=D, K=hid, A=ws.hd, lda=hid, W=blk["fc2_w"], bias=blk["fc2_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
-                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL | EP_ROWSTATS, out_f32=ws.x, ldo_f32=D, out_op=ws.y, ldo_op=D, rowstat_out=ws.part)
-                    k_rowstats_finalize(ws.part, T, G, LN_EPS, ws.stats)
+            k_igemm(M=T, N=D, k_alg=D, A=ws.o, W=blk["proj_w"], bias=blk["proj_b"], gamma=blk["ls1"], res=ws.x, ldr=D,
+                    flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, D))
+            k_layernorm(ws.x, D, T, D, blk["ln2_w"], blk["ln2_b"], LN_EPS, out_op=ws.y, ld_op=ldy, split_seg=seg(blk))
+            if w.ffn == "mlp":
+                k_igemm(M=T, N=hid, k_alg=D, A=ws.y, W=blk["fc1_w"], bias=blk["fc1_b"], flags=EP_BIAS | EP_GELU,
+                        out_op=ws.hd, ldo_op=hid, **a_ln(blk, "fc1_w"))
+                k_igemm(M=T, N=D, k_alg=hid, A=ws.hd, W=blk["fc2_w"], bias=blk["fc2_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
+                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, hid))
             else:
-                tail2 = lntail(blk, "ln2_w", "ln2_b")
-                k_igemm(M=T, N=D, k_alg=D, A=ws.o, W=blk["proj_w"], bias=blk["proj_b"], gamma=blk["ls1"], res=ws.x, ldr=D,
-                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, D), **tail2)
-                if not tail2:
-                    k_layernorm(ws.x, D, T, D, blk["ln2_w"], blk["ln2_b"], LN_EPS, out_op=ws.y, ld_op=ldy, split_seg=seg(blk))
-                # the next block's norm1 rides on this block's fc2 / w3 -- unless this is a tap block (its tap LayerNorm emits norm1 as a second output)
-                tail1 = {} if (last or i in taps) else lntail(w.blocks[i + 1], "ln1_w", "ln1_b")
-                if tail1:
-                    ln1_done = True
-                if w.ffn == "mlp":
-                    k_igemm(M=T, N=hid, k_alg=D, A=ws.y, W=blk["fc1_w"], bias=blk["fc1_b"], flags=EP_BIAS | EP_GELU,
-                            out_op=ws.hd, ldo_op=hid, **a_ln(blk, "fc1_w"))
-                    k_igemm(M=T, N=D, k_alg=hid, A=ws.hd, W=blk["fc2_w"], bias=blk["fc2_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
-                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, hid), **tail1)
-                else:
-                    k_igemm(M=T, N=2 * hid, k_alg=D, A=ws.y, W=blk["w12_w"], bias=blk["w12_b"], flags=EP_BIAS | EP_SWIGLU,
-                            out_op=ws.hd, ldo_op=hid, **a_ln(blk, "w12_w"))
-                    k_igemm(M=T, N=D, k_alg=hid, A=ws.hd, W=blk["w3_w"], bias=blk["w3_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
-                            flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, hid), **tail1)
+                k_igemm(M=T, N=2 * hid, k_alg=D, A=ws.y, W=blk["w12_w"], bias=blk["w12_b"], flags=EP_BIAS | EP_SWIGLU,
+                        out_op=ws.hd, ldo_op=hid, **a_ln(blk, "w12_w"))
+                k_igemm(M=T, N=D, k_alg=hid, A=ws.hd, W=blk["w3_w"], bias=blk["w3_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
+                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, hid))
+            if self.block_probe is not None:      # diagnostic (tools/stage_errors.py): the residual stream behind block i
+                self.block_probe(i, ws)
             if i in taps:  # shared final LayerNorm on the tap, cls row dropped (dinov2.py:337-340)
                 tap = ws.taps[taps.index(i)]
-                if not last and not fold:
+                if not last:
                     # the next block's norm1 (block.py:84) reads the very rows this LayerNorm reads: one pass over x, two outputs with the
                     # same statistics -- norm1(x) for all T rows into ws.y, norm(x) without the cls rows into the tap
                     nb = w.blocks[i + 1]
@@ -1097,8 +1047,7 @@ class DepthEngine:
         # ---- resize x2 -> output_conv1 (dpt.py:192-193) -> resize to (14 ph, 14 pw) -> output_conv2 (3x3, ReLU, 1x1, activation) (:194-195) ----
         if w.oc1c is not None:
             ntap = 9 * ws.half
-            tout = dict(out_f32=ws.tmaps, ldo_f32=ntap) if ws.tmaps.dtype == torch.float32 else dict(out_op=ws.tmaps, ldo_op=ntap)
-            k_igemm(M=rows[0], N=ntap, K=2 * Fp, a_wrap=Fp, k_alg=Fch, A=ws.u[0], lda=Fp, W=w.oc1c["w"], bias=w.oc1c["b"], flags=EP_BIAS, **tout)
+            k_igemm(M=rows[0], N=ntap, K=2 * Fp, a_wrap=Fp, k_alg=Fch, A=ws.u[0], lda=Fp, W=w.oc1c["w"], bias=w.oc1c["b"], flags=EP_BIAS, out_op=ws.tmaps, ldo_op=ntap)
             k_tapsum_resize(ws.tmaps, ntap, B, grid[0][0], grid[0][1], g2[0], g2[1], ws.half, w.oc1_b, ws.oc1, ws.half)
         else:
             k_bilinear(ws.zf[0], Fch, B, grid[0][0], grid[0][1], g2[0], g2[1], Fch, out_op=ws.p1, ld_op=ws.p1.shape[3], map_op=MAP_PAD, split_seg=S("oc1", Fp))

@@ -108,17 +108,6 @@ class DPTHead(nn.Module):
 
 import os as _os
 
-# Folding the block LayerNorms into qkv / fc1 (PackedWeights.fold_ln) is built and parity-tested but OFF by default: on MI355X at
-# ViT-L bs=32 it removes 47 LayerNorm launches (-2.0 ms) and adds 2.3 ms to the GEMM epilogues that take over their work (the extra
-# operand-typed store of the residual stream, the row-statistics shuffles, the per-row rescale), with 7 % more parity error
-# (profiles/r02_e_layernorm_fold_ab.txt).  ADA_FOLD_LN=1 or ``module.fold_layernorm = True`` turns it on.
-# CAVEAT (why it is an experiment switch, not a product option): the folded path feeds the UN-normalised residual stream to qkv / fc1 as fp16
-# operands and takes the variance as E[x^2] - mean^2 from per-64-column partial sums.  That is fine for the O(1) activations of the synthetic
-# fills; a real DINOv2 checkpoint with massive-activation channels (hundreds) loses accuracy on both counts (cancellation in the variance,
-# operand rounding relative to the outlier).  Check DepthEngine.saturation_report and the parity of your checkpoint before enabling it.
-_FOLD_LN_DEFAULT = _os.environ.get("ADA_FOLD_LN", "0") == "1"
-
-
 # Head precision policy for "auto" (measured on MI355X against the reference goldens, profiles/r03_e_head_split_sweep.txt):
 #   sigmoid heads of ViT-B / ViT-L (the benchmarked models)  -> single precision but the 1x1 out_convs of refinenet2-4 (round 4) and, on ViT-L, the
 #                                                               projects' weights ("projw", round 4)
@@ -148,9 +137,11 @@ def _rung1_proj_f8():
 _RAW_VITG_SPLIT = ("oc1", "oc2", "out", "rn1", "rn2", "rn3", "proj", "rs1", "rs3")
 
 
-def _head_split_policy(mode, encoder, final_act):
+def _head_split_policy(mode, encoder, final_act, proj_f8=None):
     """Which contractions of the DPT head (hip_ext.engine.HEAD_GROUPS / HEAD_ALIASES) run in split precision.  ``mode``: "auto" |
-    "split" (all) | "single" (none) | a comma-separated string / iterable of names.  ADA_HEAD_SPLIT overrides "auto" (experiments)."""
+    "split" (all) | "single" (none) | a comma-separated string / iterable of names.  ADA_HEAD_SPLIT overrides "auto" (experiments).
+    ``proj_f8``: whether the sigmoid ViT-B / ViT-L first rung runs its projects as a full split product with fp8 correction terms (None: where
+    the build offers them, _rung1_proj_f8) -- False when the caller's ``f8_terms`` keeps the head off the fp8 pipe: the round-4 policy then."""
     from hip_ext.engine import HEAD_GROUPS
     if mode == "auto" and _os.environ.get("ADA_HEAD_SPLIT") is not None:
         mode = _os.environ["ADA_HEAD_SPLIT"]
@@ -166,7 +157,7 @@ def _head_split_policy(mode, encoder, final_act):
             # ViT-L also runs its four 1x1 projects against [w_hi | w_lo] weights ("projw", weight-only split: 2x their 0.25 TFLOP per bs=32 step,
             # 0.4 % of it): the heavy-tailed 714 x 1022 stress fixture 8.9e-4 -> 6.9e-4, the benchmarked batch 6.17e-4 -> 5.94e-4; on ViT-B the
             # projects are not where the noise sits (9.0e-4 -> 8.8e-4 on its stress fixture, profiles/r04_r_*), so it keeps the three out_convs only
-            if _rung1_proj_f8():
+            if _rung1_proj_f8() if proj_f8 is None else proj_f8:
                 return frozenset(_SIGMOID_SPLIT + ("proj",))
             return frozenset(_SIGMOID_SPLIT + (("projw",) if encoder == "vitl" else ()))
         if final_act == "relu" and encoder == "vitg":
@@ -307,7 +298,7 @@ class _EngineMixin:
         hp = getattr(self, "head_precision", "auto")
         ladder_r = _ladder_threshold(self, self.encoder, self.depth_head.final_act, hp)
         f8 = getattr(self, "f8_terms", None) or _f8_policy(self.depth_head.final_act)     # module.f8_terms: "both" | "enc" | "head" | "none" overrides the policy
-        stamp = tuple((v.data_ptr(), v._version) for v in plist) + (hp if isinstance(hp, str) else tuple(sorted(hp)), getattr(self, "fold_layernorm", _FOLD_LN_DEFAULT),
+        stamp = tuple((v.data_ptr(), v._version) for v in plist) + (hp if isinstance(hp, str) else tuple(sorted(hp)),
                                                                       getattr(self, "encoder_precision", "auto"), ladder_r, f8,
                                                                       _flat_input_rung(self, self.depth_head.final_act, hp if isinstance(hp, str) else "groups"))
         if getattr(self, "_engine_stamp", None) != stamp:
@@ -319,18 +310,25 @@ class _EngineMixin:
             # ladder (DepthEngine._escalate): images whose depth map sits where the sigmoid does not compress the logit error get the head re-run
             # in split precision.
             mode = getattr(self, "head_precision", "auto")
-            split = _head_split_policy(mode, self.encoder, self.depth_head.final_act)
+            # ONE decision for everything that touches the fp8 form on the sigmoid ViT-B / ViT-L models (with module.f8_terms = "none" / "enc"
+            # the first rung's "proj" split, the taps' [hi | lo8 | hi8] form and the fp16-packed weights used to be derived separately and met in _kdup
+            # as "three-term fp16 weights against a [hi | lo8 | hi8] operand"): the caller's f8_terms, when given, rules the first rung's projects, the
+            # second rung's weights, the form of the taps between them and the third rung alike.
+            f8_user = getattr(self, "f8_terms", None)
+            head_f8_ok = f8_user is None or f8_user in ("head", "both")
+            rung1_f8 = (mode == "auto" and self.depth_head.final_act == "sigmoid" and self.encoder != "vits" and _rung1_proj_f8() and head_f8_ok)
+            ladder_f8 = _LADDER_F8 if f8_user is None else ("head" if head_f8_ok else "none")
+            split = _head_split_policy(mode, self.encoder, self.depth_head.final_act, proj_f8=rung1_f8)
             guided, amodal_head = self.pretrained.has_guidance, hasattr(self.depth_head, "input_projection")
             enc_split = _encoder_split_policy(getattr(self, "encoder_precision", "auto"), self.encoder, self.depth_head.final_act)
             f8_only = None
             # the first rung of the sigmoid ViT-B / ViT-L heads (ladder on or off; an explicit head_precision or f8_terms is the caller's choice)
-            if (getattr(self, "f8_terms", None) is None and mode == "auto" and "proj" in split and self.depth_head.final_act == "sigmoid"
-                    and self.encoder != "vits" and _rung1_proj_f8()):
+            if f8_user is None and rung1_f8 and "proj" in split:
                 f8, f8_only = "head", ("proj",)
             pw = PackedWeights(sd, self.encoder, guided=guided, amodal_head=amodal_head,
-                               split_head=split, fold_ln=bool(getattr(self, "fold_layernorm", _FOLD_LN_DEFAULT)),
+                               split_head=split,
                                enc_split_blocks=enc_split, tap_split=ladder_r is not None, f8=f8, f8_only=f8_only,
-                               tap_f8=(_LADDER_F8 in ("both", "head")) if ladder_r is not None else None)
+                               tap_f8=(ladder_f8 in ("both", "head")) if ladder_r is not None else None)
             ladder = None
             if ladder_r is not None:
                 encoder = self.encoder
@@ -339,8 +337,8 @@ class _EngineMixin:
                 every = tuple(g for g in HEAD_GROUPS if g != "projw")
 
                 def third():
-                    return DepthEngine(PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=every, enc_split_blocks=depth, f8="both"), final_act, norm_in)
-                ladder = dict(r=ladder_r, div=_LADDER_DIV, make=lambda: PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=groups, head_only=True, f8=_LADDER_F8),
+                    return DepthEngine(PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=every, enc_split_blocks=depth, f8=f8_user or "both"), final_act, norm_in)
+                ladder = dict(r=ladder_r, div=_LADDER_DIV, make=lambda: PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=groups, head_only=True, f8=ladder_f8),
                               r3=max(_LADDER_R3, ladder_r), make3=third)
             if ladder is None and _flat_input_rung(self, self.depth_head.final_act, mode):
                 final_act, norm_in, depth, encoder, f8_ = self.depth_head.final_act, bool(getattr(self, "normalise_input", False)), len(self.pretrained.blocks), self.encoder, f8

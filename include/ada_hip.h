@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADA_ABI_VERSION 7   /* 6 (round 5): + ada_depth_stats_fwd, ada_token_diversity_fwd; 7: ada_igemm_args grows f8_from / f8_mid / f8_scales at its end and split_seg < 0 names the fp8 form of a split output (a zero-filled tail = off: every ABI-6 call means what it meant) */
+#define ADA_ABI_VERSION 8   /* 8 (round 6): the default-off experiment paths that lost are gone -- ada_igemm_args without ln_stats / ln_colsum / rowstat_out (EP_LNFOLD / EP_ROWSTATS) and the LayerNorm tail (ln_*), no ada_rowstats_finalize.  History: 6 (round 5): + ada_depth_stats_fwd, ada_token_diversity_fwd; 7: ada_igemm_args grows f8_from / f8_mid / f8_scales at its end and split_seg < 0 names the fp8 form of a split output (a zero-filled tail = off: every ABI-6 call means what it meant) */
 
 /* status codes */
 #define ADA_OK 0
@@ -91,10 +91,7 @@ const char* ada_last_error(void);
 #define ADA_EP_SWIGLU 0x20   /* columns come in (x1, x2) 32-wide groups: out = silu(x1) * x2 */
 #define ADA_EP_TAIL 0x40     /* v = relu(v); d = sum_n v*tail_w[n] + tail_b; out_f32[m] = act(d) */
 #define ADA_EP_RELU_F32 0x80 /* ReLU applied to the fp32 output as well */
-#define ADA_EP_ROWSTATS 0x100 /* also store per-row partial (sum, sum of squares) of the fp32 result: rowstat_out */
-#define ADA_EP_LNFOLD 0x200  /* A is the UN-normalised row, W carries the LayerNorm gain:
-                                v = rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n]   (block.py:84,87 folded into
-                                attention.py:51 / mlp.py:36; see ada_rowstats_finalize) */
+/* (0x100, 0x200: ADA_EP_ROWSTATS / ADA_EP_LNFOLD of ABI <= 7 -- the LayerNorm folded into its consumer, a measured loss -- are gone; the bits stay unused) */
 
 /* tail activations */
 #define ADA_ACT_NONE 0
@@ -128,9 +125,6 @@ typedef struct ada_igemm_args {
     const float* tail_w;    /* TAIL: [N] fp32 */
     float tail_b;
     int32_t tail_act;
-    const float* ln_stats;  /* LNFOLD: fp32 [M, 2] = (mean, rstd) per row (ada_rowstats_finalize) */
-    const float* ln_colsum; /* LNFOLD: fp32 [N], sum over k of the operand-typed, gain-folded weights W'[n, k] */
-    float* rowstat_out;     /* ROWSTATS: fp32 [M, N/64, 2], (sum, sum of squares) of the fp32 result over each 64-column group */
     int32_t split_seg;      /* > 0: split-precision op output -- out_op receives [hi | lo] in two column segments of
                                split_seg elements (hi = round(v), lo = round(v - hi)); 0 = plain;
                                < 0: the fp8 form of the same, seg = -split_seg: [hi: seg elements | lo8: seg bytes | hi8: seg bytes], see f8_from */
@@ -154,17 +148,6 @@ typedef struct ada_igemm_args {
                                use_clstoken read-out (DA2/dpt.py:110-117,164-167: Linear(2D, D) on [patch | class token] + GELU) is a D -> D GEMM over
                                the patch tokens whose bias W_cls cls_b + b differs per image: one launch for the whole batch.  Operand-typed output
                                only (bias / GELU epilogues).  0 = one bias vector [N] */
-    /* LayerNorm tail (ln_out != NULL): the LayerNorm that follows the contraction -- norm2 behind attn.proj, the next block's norm1 behind mlp.fc2
-       (DA2/dinov2_layers/block.py:84,87) -- reads the rows this launch writes to out_f32.  With N = the whole LayerNorm row, the last of a row
-       panel's tiles to finish normalises the panel (biased variance, eps inside the sqrt) and writes ln_out[m, :N] operand-typed: no separate
-       ada_layernorm_fwd launch.  ln_counter: device uint32[ceil(M / 128)], zero before the first use; the kernel returns it to zero.
-       Inter-workgroup protocol: write-through stores, drained, one agent-scope ticket per tile; the reader loads sc1. */
-    const float* ln_weight;
-    const float* ln_bias;
-    float ln_eps;
-    void* ln_out;
-    int64_t ld_ln;
-    void* ln_counter;
     /* fp8 correction terms of a split-precision product (gfx950 v_mfma_scale_f32_16x16x128_f8f6f4, twice the fp16 matrix rate):
          x w  ~  x_hi w_hi  +  2^-10 x_lo8 w_hi8  +  x_hi8 w_lo8          (instead of three fp16 products, a_dup_seg)
        f8_from > 0: inside each period of the k-walk -- all K operand slots of a PLAIN operand, one tap (lda slots) of a CONV3 one -- the slots from
@@ -173,17 +156,12 @@ typedef struct ada_igemm_args {
        byte e multiplies its operand by 2^(e - 127) (E8M0).  The A layout [hi: seg slots | lo8: seg bytes | hi8: seg bytes] is what a producer writes
        for split_seg = -seg (lo8 = e5m2((v - hi) 2^10), hi8 = e5m2(v)); the weights are packed [w_hi | w_hi8 | w_lo8] with per-tensor power-of-two
        scales: K = 2 seg (x 9), f8_from = seg, f8_mid = 3 seg / 2, f8_scales = 117 | sb_hi << 8 | 127 << 16 | sb_lo << 24.  f8_from, f8_mid: multiples
-       of 64.  Excludes a_dup_seg / a_wrap / EP_LNFOLD.  0 = off */
+       of 64.  Excludes a_dup_seg / a_wrap.  0 = off */
     int32_t f8_from, f8_mid;
     uint32_t f8_scales;
 } ada_igemm_args;
 
 int ada_igemm(const ada_igemm_args* args, void* stream);
-
-/* Finishes the row statistics an ADA_EP_ROWSTATS epilogue left behind: partials fp32 [rows, groups, 2] (sum, sum of squares
- * per 64-column group) -> stats fp32 [rows, 2] = (mean, 1 / sqrt(var + eps)) over dim = 64 * groups columns, biased variance
- * (nn.LayerNorm, DA2/dinov2_layers/block.py:84,87).  The consumer is an ADA_EP_LNFOLD contraction. */
-int ada_rowstats_finalize(const float* partials, int32_t rows, int32_t groups, float eps, float* stats, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused scaled-dot-product attention, head_dim 64 (all of ViT-S/B/L/G):

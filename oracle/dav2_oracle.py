@@ -159,8 +159,8 @@ def encoder_taps(nm, sd, pfx, encoder, x, guide, trace=None, return_class_token=
     outs = []
     for i in range(cfg["depth"]):
         t = block(nm, sd, f"{pfx}blocks.{i}.", t, cfg["heads"], cfg["ffn"])
-        if trace is not None and i == 0:
-            trace["block0"] = t
+        if trace is not None and (i == 0 or trace.get("_every_block")):      # "_every_block": the residual stream behind every block (tools/stage_errors.py)
+            trace[f"block{i}"] = t
         if i in TAPS[encoder]:
             outs.append(t)
     normed = [F.layer_norm(o, (D,), sd[pfx + "norm.weight"], sd[pfx + "norm.bias"], LN_EPS) for o in outs]

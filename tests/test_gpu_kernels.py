@@ -357,48 +357,6 @@ def test_igemm_bias_per_row_group(hip, forced_tile, G, rows, N, K, cfg, gelu):
     _close(out[:, :N].float() + out[:, N:].float(), ref, 2e-5 if op == torch.float16 else 3e-4, rtol=2e-5 if op == torch.float16 else 3e-4, what="per-group bias (hi + lo)")
 
 
-@pytest.mark.parametrize("M,N,K,cfg", [(4110, 1024, 256, -1), (4110, 1024, 256, 3), (2740, 768, 128, 4), (1370, 384, 192, 1), (700, 1536, 64, 2), (5000, 1024, 1024, 3), (257, 256, 64, -1)])
-def test_igemm_layernorm_tail(hip, forced_tile, M, N, K, cfg):
-    """ada_igemm_args.ln_out: the last-arriving tile of each row panel normalises the rows the launch has just written (inter-workgroup hand-off inside
-    one launch: write-through stores, drained, one agent-scope ticket per tile, sc1 loads on the reader).  Every word of the LayerNorm output is checked
-    against the stand-alone kernel on the same fp32 rows, 12 launches per shape with a second stream loading the memory system on every other one
-    (uneven load is what exposes a missing release / acquire), and the tickets must be back at zero after every launch."""
-    op = _op(hip)
-    A = _rand(M, K, seed=81).to(op).to(DEV)
-    W = (_rand(N, K, seed=82) * K ** -0.5).to(op).to(DEV)
-    b, g = _rand(N, seed=83).to(DEV), (0.3 + 0.7 * torch.rand(N, generator=torch.Generator().manual_seed(84))).to(DEV)
-    lw, lb = (1.0 + 0.1 * _rand(N, seed=85)).to(DEV), (0.1 * _rand(N, seed=86)).to(DEV)
-    cnt = torch.zeros(M // 128 + 2, dtype=torch.int32, device=DEV)
-    side = torch.cuda.Stream()
-    noise = torch.randn(1 << 25, device=DEV)
-    if cfg >= 0:
-        forced_tile(cfg, 0)
-    for rep in range(12):
-        x0 = _rand(M, N, seed=90 + rep).to(DEV)
-        x_ref, x_tail = x0.clone(), x0.clone()
-        y_tail = torch.full((M, N), float("nan"), dtype=op, device=DEV)
-        kw = dict(M=M, N=N, K=K, A=A, lda=K, W=W, bias=b, gamma=g, ldr=N, flags=hip.EP_BIAS | hip.EP_GAMMA | hip.EP_RESIDUAL, ldo_f32=N)
-        hip.igemm(res=x_ref, out_f32=x_ref, **kw)
-        y_ref = torch.empty(M, N, dtype=op, device=DEV)
-        hip.layernorm(x_ref, N, M, N, lw, lb, 1e-6, out_op=y_ref, ld_op=N)
-        if rep & 1:
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    noise.mul_(1.0001)
-        hip.igemm(res=x_tail, out_f32=x_tail, ln_weight=lw, ln_bias=lb, ln_eps=1e-6, ln_out=y_tail, ld_ln=N, ln_counter=cnt, **kw)
-        torch.cuda.current_stream().wait_stream(side)
-        assert torch.equal(x_tail, x_ref), f"rep {rep}: the fp32 rows differ from the launch without the tail"
-        assert int(cnt.abs().sum()) == 0, f"rep {rep}: tickets not returned to zero"
-        d = (y_tail.float() - y_ref.float()).abs()
-        assert torch.isfinite(y_tail.float()).all(), f"rep {rep}: {int((~torch.isfinite(y_tail.float())).sum())} rows never normalised"
-        # same rows, same formula; the mean is s * (1 / N) here and s / N there: at most one operand ulp apart
-        bad = d > 2e-3 * y_ref.float().abs() + 2e-3
-        assert not bad.any(), f"rep {rep}: {int(bad.sum())} of {bad.numel()} LayerNorm outputs differ (max {float(d.max()):.3e}) -- stale rows?"
-    ref = F.layer_norm(x_ref.cpu(), (N,), lw.cpu(), lb.cpu(), 1e-6)
-    _close(y_tail, ref, 4e-3 if op == torch.float16 else 3e-2, rtol=4e-3 if op == torch.float16 else 2e-2, what="LayerNorm tail vs torch")
-
-
 def test_layernorm_second_output_drops_cls_rows(hip):
     """One pass, two normalised outputs of the same rows: all rows with (gain, bias) 1 -> the next block's LN1; the rows of every group of N
     but the first with (gain, bias) 2, compacted -> the tap LayerNorm (DA2/dinov2.py:337-340)."""
@@ -988,61 +946,6 @@ def test_igemm_split_output_plain_pad_shuffle(hip, forced_tile, cfg):
               map_h=5, map_w=6, shuffle_s=s_, shuffle_c=Co, split_seg=segc)
     ref = F.conv_transpose2d(xs, wt, stride=s_).permute(0, 2, 3, 1)
     _check_split(o[:, 1:-1, 1:-1], ref, Co, segc, op, f"igemm split shuffle cfg {cfg}", exact=False)
-
-
-# =====================================================================================================================
-# LayerNorm folded into the consuming contraction (ADA_EP_LNFOLD) + row statistics from the producing epilogue (ADA_EP_ROWSTATS)
-# =====================================================================================================================
-@pytest.mark.parametrize("cfg", [-1, 3, 4, 1, 2])
-@pytest.mark.parametrize("gelu", [False, True])
-def test_igemm_layernorm_fold_pipeline(hip, forced_tile, cfg, gelu):
-    """x_new = x + (A W_p^T + b_p) * ls  (producer: fp32 residual stream, operand-typed copy, row statistics)  ->  finalize  ->
-    y = act(LN(x_new) W^T + b)  (consumer with the gain folded into W): against the same thing computed with torch in fp32."""
-    op = _op(hip)
-    if cfg >= 0:
-        forced_tile(cfg, 4)
-    M, D, Kp, N = 3 * 256 + 70, 256, 128, 320
-    A = _rand(M, Kp, seed=401).to(op).to(DEV)
-    Wp = (_rand(D, Kp, seed=402) * Kp ** -0.5).to(op).to(DEV)
-    bp, ls = _rand(D, seed=403).to(DEV), (_rand(D, seed=404) * 0.3 + 1).to(DEV)
-    x = (_rand(M, D, seed=405) * 2 + 0.7).to(DEV)           # rows with a non-zero mean
-    x_ref = x.cpu() + (A.float().cpu() @ Wp.float().cpu().T + bp.cpu()) * ls.cpu()
-    xh = torch.zeros(M, D, dtype=op, device=DEV)
-    part = torch.full((M, D // 64, 2), float("nan"), device=DEV)
-    hip.igemm(M=M, N=D, K=Kp, A=A, lda=Kp, W=Wp, bias=bp, gamma=ls, res=x, ldr=D, flags=hip.EP_BIAS | hip.EP_GAMMA | hip.EP_RESIDUAL | hip.EP_ROWSTATS,
-              out_f32=x, ldo_f32=D, out_op=xh, ldo_op=D, rowstat_out=part)
-    _close(x, x_ref, 3e-4, what="producer f32")
-    _close(xh, x_ref, 2e-3, rtol=1e-2 if op == torch.bfloat16 else 2e-3, what="producer op copy")
-    xg = x.cpu().reshape(M, D // 64, 64)
-    _close(part[..., 0], xg.sum(-1), 2e-4, rtol=1e-5, what="row sums")
-    _close(part[..., 1], (xg * xg).sum(-1), 2e-3, rtol=1e-5, what="row sums of squares")
-    stats = torch.zeros(M, 2, device=DEV)
-    hip.rowstats_finalize(part, M, D // 64, 1e-6, stats)
-    mu, var = x.cpu().mean(1), x.cpu().var(1, unbiased=False)
-    _close(stats[:, 0], mu, 1e-5, rtol=1e-5, what="mean")
-    _close(stats[:, 1], (var + 1e-6).rsqrt(), 1e-5, rtol=2e-5, what="rstd")
-    # consumer
-    g, beta = (_rand(D, seed=406) * 0.2 + 1), _rand(D, seed=407) * 0.3
-    W = _rand(N, D, seed=408) * D ** -0.5
-    b = _rand(N, seed=409)
-    wf = (W * g[None, :]).to(op)
-    colsum = wf.float().sum(1).contiguous()
-    const = (b + W @ beta).contiguous()
-    out = torch.zeros(M, N, dtype=op, device=DEV)
-    hip.igemm(M=M, N=N, K=D, A=xh, lda=D, W=wf.to(DEV), bias=const.to(DEV), ln_stats=stats, ln_colsum=colsum.to(DEV),
-              flags=hip.EP_BIAS | hip.EP_LNFOLD | (hip.EP_GELU if gelu else 0), out_op=out, ldo_op=N)
-    ref = F.layer_norm(x.cpu(), (D,), g, beta, 1e-6) @ W.T + b
-    if gelu:
-        ref = F.gelu(ref)
-    # reference with the unfolded arithmetic on operand-rounded LN output (what the stand-alone LayerNorm path computes)
-    ref_unf = F.layer_norm(x.cpu(), (D,), g, beta, 1e-6).to(op).float() @ W.to(op).float().T + b
-    if gelu:
-        ref_unf = F.gelu(ref_unf)
-    e_fold = float((out.float().cpu() - ref).abs().mean() / ref.abs().mean())
-    e_unf = float((ref_unf.to(op).float() - ref).abs().mean() / ref.abs().mean())
-    print(f"cfg {cfg} gelu {gelu}: folded rel-L1 {e_fold:.2e} vs stand-alone LayerNorm path {e_unf:.2e}")
-    assert e_fold < max(2.0 * e_unf, 1e-3 if op == torch.float16 else 8e-3)
-    _close(out, ref, 6e-3, rtol=2e-2 if op == torch.bfloat16 else 6e-3, what="folded LN consumer")
 
 
 # =====================================================================================================================

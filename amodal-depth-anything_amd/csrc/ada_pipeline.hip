@@ -37,7 +37,8 @@ __global__ __launch_bounds__(1024) void minmax_kernel(const float* __restrict__ 
 // L1 of a sigmoid output against its fp32 reference is  mean|sigma'(z) dz| / mean s = mean(s (1 - s) |dz|) / mean(s): the ratio of the two sums is the
 // factor by which the sigmoid compresses the head's logit error for THIS image (0.3-0.5 for maps centred in (0, 1), -> 1 as the map approaches 0).
 // grid (chunks, batch): every workgroup sums a contiguous chunk in a fixed order (no atomics: bit-reproducible); the host adds the chunk sums.
-__global__ __launch_bounds__(1024) void depth_stats_kernel(const float* __restrict__ in, long n_per_image, float* __restrict__ out) {
+// act (the final activation of the head, ADA_ACT_*): SIGMOID (sum s, sum s (1 - s)); RELU (sum out, number of positive outputs); NONE (sum |out|, number of outputs)
+__global__ __launch_bounds__(1024) void depth_stats_kernel(const float* __restrict__ in, long n_per_image, int act, float* __restrict__ out) {
     __shared__ float s1[16], s2[16];
     const int chunks = gridDim.x, c = blockIdx.x, b = blockIdx.y;
     const long per = (n_per_image + chunks - 1) / chunks;
@@ -46,8 +47,16 @@ __global__ __launch_bounds__(1024) void depth_stats_kernel(const float* __restri
     float a = 0.0f, q = 0.0f;
     for (long i = lo + threadIdx.x; i < hi; i += 1024) {
         const float v = src[i];
-        a += v;
-        q += v * (1.0f - v);
+        if (act == ADA_ACT_SIGMOID) {
+            a += v;
+            q += v * (1.0f - v);
+        } else if (act == ADA_ACT_RELU) {
+            a += v;
+            q += v > 0.0f ? 1.0f : 0.0f;
+        } else {
+            a += __builtin_fabsf(v);
+            q += 1.0f;
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -210,10 +219,10 @@ extern "C" int ada_minmax_fwd(const float* in, int32_t batch, int64_t n_per_imag
     return ada_check_launch("ada_minmax_fwd");
 }
 
-extern "C" int ada_depth_stats_fwd(const float* in, int32_t batch, int64_t n_per_image, int32_t chunks, float* sums, void* stream) {
+extern "C" int ada_depth_stats_fwd(const float* in, int32_t batch, int64_t n_per_image, int32_t chunks, int32_t act, float* sums, void* stream) {
     ADA_REQUIRE(in && sums, ADA_EINVAL, "ada_depth_stats_fwd: null pointer");
-    ADA_REQUIRE(batch > 0 && batch <= 65535 && n_per_image > 0 && chunks > 0 && chunks <= 1024, ADA_EINVAL, "ada_depth_stats_fwd: bad shape (batch=%d chunks=%d)", batch, chunks);
-    hipLaunchKernelGGL(depth_stats_kernel, dim3(chunks, batch), dim3(1024), 0, (hipStream_t)stream, in, (long)n_per_image, sums);
+    ADA_REQUIRE(batch > 0 && batch <= 65535 && n_per_image > 0 && chunks > 0 && chunks <= 1024 && act >= ADA_ACT_NONE && act <= ADA_ACT_RELU, ADA_EINVAL, "ada_depth_stats_fwd: bad shape (batch=%d chunks=%d)", batch, chunks);
+    hipLaunchKernelGGL(depth_stats_kernel, dim3(chunks, batch), dim3(1024), 0, (hipStream_t)stream, in, (long)n_per_image, (int)act, sums);
     return ada_check_launch("ada_depth_stats_fwd");
 }
 

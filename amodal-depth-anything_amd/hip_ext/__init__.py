@@ -124,7 +124,7 @@ def load(path: Optional[str] = None):
     lib.ada_selftest.restype = c_int
     lib.ada_minmax_fwd.argtypes = [c_void_p, c_int32, c_int64, c_void_p, c_void_p]
     lib.ada_minmax_fwd.restype = c_int
-    lib.ada_depth_stats_fwd.argtypes = [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]
+    lib.ada_depth_stats_fwd.argtypes = [c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p]
     lib.ada_depth_stats_fwd.restype = c_int
     lib.ada_token_diversity_fwd.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]
     lib.ada_token_diversity_fwd.restype = c_int
@@ -348,10 +348,11 @@ def minmax(inp, minmax_out):
            "ada_minmax_fwd")
 
 
-def depth_stats(inp, sums):
-    """inp: fp32 [B, ...] contiguous sigmoid-head depth maps -> sums fp32 [B, chunks, 2] = per-chunk (sum s, sum s (1 - s)) (ada_depth_stats_fwd)."""
+def depth_stats(inp, sums, act=ACT_SIGMOID):
+    """inp: fp32 [B, ...] contiguous depth maps of a head that ends in `act` -> sums fp32 [B, chunks, 2], per chunk (sum s, sum s (1 - s)) for a sigmoid,
+    (sum out, number of positive outputs) for a ReLU, (sum |out|, number of outputs) for none (ada_depth_stats_fwd)."""
     B = inp.shape[0]
-    _check(load().ada_depth_stats_fwd(_dev(inp, "in", torch.float32), B, inp.numel() // B, sums.shape[1], _dev(sums, "sums", torch.float32), _stream()),
+    _check(load().ada_depth_stats_fwd(_dev(inp, "in", torch.float32), B, inp.numel() // B, sums.shape[1], int(act), _dev(sums, "sums", torch.float32), _stream()),
            "ada_depth_stats_fwd")
 
 

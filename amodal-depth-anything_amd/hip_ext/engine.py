@@ -619,9 +619,8 @@ class DepthEngine:
         # Precision ladder of the sigmoid heads (see _escalate): dict(r=<threshold on sum s(1-s) / sum s>, make=<callable -> head-only PackedWeights
         # in split precision>) or None.  The first rung -- this engine's own weights -- must keep its taps [hi | lo] (PackedWeights.tap_split).
         # Heads without a sigmoid keep the third rung's token-diversity trigger only: dict(div=..., make3=...) (DA2/dpt.py::_flat_input_rung).
-        if ladder is not None and "r" in ladder and final_act != "sigmoid":
-            ladder = None
         self.ladder = ladder
+        self._warned = False          # the one-time notice that images are being re-run
         if self.ladder is not None and "make" in self.ladder and not weights.tap_split and "proj" not in weights.split:
             raise HipExtError("precision ladder: the engine's weights must be packed with tap_split=True")
         self._w_hi: Optional[PackedWeights] = None
@@ -777,29 +776,43 @@ class DepthEngine:
         if ws is None:
             ws = self.workspace(B, H, W, out.device)
         D = self.w.dim
-        has_r = "r" in lad           # sigmoid heads; the others watch the token diversity only
+        # r: the sensitivity of the metric to a logit error, from the output itself -- sum s(1-s) / sum s behind a sigmoid, (positive outputs) / sum out behind a
+        # ReLU (round 6: a clipped pixel carries no error; a map that is mostly clipped with the rest just above the kink has a small denominator), N / sum |out|
+        # for bare logits.  Thresholds: lad["r"] (second rung: head re-run; sigmoid policy) and lad["r3"] (third rung), both CALIBRATED per checkpoint (calibrate()).
+        has_r = "r" in lad or "r3" in lad
+        has_div = lad.get("div", 0.0) > 0.0
         if has_r:
-            k_depth_stats(out, ws.stat_sums)
-        k_token_diversity(ws.taps[3], ws.taps[3].shape[1], B, ws.ph * ws.pw, D, ws.stat_div)
+            k_depth_stats(out, ws.stat_sums, self.final_act)
+        if has_div:
+            k_token_diversity(ws.taps[3], ws.taps[3].shape[1], B, ws.ph * ws.pw, D, ws.stat_div)
         if ws.stat_in is not None:
             k_token_diversity(ws.a_pe, ws.a_pe.shape[1], B, ws.ph * ws.pw, self.w.pe_seg, ws.stat_in)
         host = ws.stat_buf.cpu().double()                       # the forward's one synchronisation: (8 + D / 64 + patch width / 64) x 2 floats per image
         nst, ndv = B * STAT_CHUNKS * 2, B * ((D + 63) // 64) * 2
         st, dv = host[:nst].view(B, STAT_CHUNKS, 2).sum(1), host[nst:nst + ndv].view(B, -1, 2).sum(1)
         ratio = st[:, 1] / st[:, 0].clamp_min(1e-300) if has_r else torch.zeros(B, dtype=torch.float64)
-        diversity = dv[:, 0] / dv[:, 1].clamp_min(1e-300)
-        self.last_ratio, self.last_diversity = ratio, diversity
-        flat = diversity < lad.get("div", 0.0)
+        self.last_ratio = ratio if has_r else None
+        flat = torch.zeros(B, dtype=torch.bool)
+        self.last_diversity = None
+        if has_div:
+            self.last_diversity = dv[:, 0] / dv[:, 1].clamp_min(1e-300)
+            flat = self.last_diversity < lad["div"]
         if ws.stat_in is not None:
             # input-side trigger: the patches of the image are all alike (variance over patches below 1e-4 of their mean square) -- the raw models' last tap does not
             # tell (synthetic raw ViT-B at 518^2: token diversity 0.18 on an all-zero image, 0.11 on a noise image; profiles/r05_aa_*), the input does
             di = host[nst + ndv:].view(B, -1, 2).sum(1)
             self.last_input_diversity = di[:, 0] / di[:, 1].clamp_min(1e-300)
             flat = flat | (self.last_input_diversity < lad.get("div_in", 1e-4))
-        trigger = ((ratio > lad["r"]) if has_r else torch.zeros_like(flat)) | flat
+        trigger = ((ratio > lad["r"]) if ("r" in lad and "make" in lad) else torch.zeros_like(flat)) | (flat if "make" in lad else torch.zeros_like(flat))
         # constant / checkerboard inputs take the third rung too: their rounding errors add coherently in the ENCODER as well (ViT-B, all-zero image at 126 x 154:
         # 8.5e-4 with the head in split precision, 2.3e-4 with everything), and what a degenerate input costs does not matter
         top = (((ratio > lad["r3"]) if "r3" in lad else torch.zeros_like(flat)) | flat) if ("make3" in lad and x is not None) else torch.zeros_like(trigger)
+        if not self._warned and bool((trigger | top).any()):
+            self._warned = True
+            import warnings
+            warnings.warn(f"precision ladder: {int((trigger | top).sum())} of {B} image(s) re-run in split precision (second rung: head only; third: whole forward) -- "
+                          f"r up to {float(ratio.max()):.3g} against thresholds {lad.get('r')} / {lad.get('r3')}; counted in DepthEngine.escalated / escalated3 "
+                          "(this message appears once per engine; module.precision_ladder = False switches the ladder off)")
         idx3 = torch.nonzero(top).flatten()
         if idx3.numel() > 0:      # third rung: the whole forward in split precision for these images, straight from the inputs
             if self._eng3 is None:
@@ -829,22 +842,105 @@ class DepthEngine:
         else:
             self._ws_hi.move_to_end(key)
         own = ws2.taps
+        own_cls = getattr(ws2, "cls_op", None)      # use_clstoken models: the read-out also reads the final-LayerNorm'd class tokens of the first rung
         try:
             if Be == B:
                 ws2.taps = ws.taps        # every image of the batch: the head reads the first rung's taps in place
+                if own_cls is not None:
+                    ws2.cls_op = ws.cls_op
             else:
                 sel = idx.to(out.device)
                 for t in range(4):
                     torch.index_select(ws.taps[t].view(B, -1), 0, sel, out=own[t].view(Be, -1))
+                    if own_cls is not None:
+                        torch.index_select(ws.cls_op[t], 0, sel, out=own_cls[t])
             hi = self._head(ws2, Be, self._w_hi)
         finally:
             ws2.taps = own
+            if own_cls is not None:
+                ws2.cls_op = own_cls
         if Be == B:
             out = hi
         else:
             out.index_copy_(0, idx.to(out.device), hi)
         self.escalated += Be
         return out
+
+    def calibrate(self, x: torch.Tensor, guide: Optional[torch.Tensor], budget: float = 8e-4, safety: float = 1.1, flat_index: Optional[int] = None) -> dict:
+        """Self-calibration of the ladder's thresholds for THIS checkpoint, on the device, with no oracle (round 6; round 5's thresholds were ~12 constants fitted
+        to synthetic weights).  The calibration images ``x`` ([0, 1] RGB; ``guide`` with the model's guide channels) run through the first rung, through the second
+        (head re-run from the first rung's taps, where the policy has one) and through the third-rung engine -- every encoder block and the whole head in split
+        precision, 1.6-3.7e-4 from the reference where it was measured -- with the final activation switched OFF, i.e. as logits z1, z2, z3.  For a grid of bias
+        shifts d (the final bias is added in fp32: moving it moves the map's operating point and nothing else) the metric of rung k against the third,
+        mean|f(z_k + d) - f(z_3 + d)| / mean f(z_3 + d), divided by the image's r (see _escalate) is the rung's sensitivity-normalised logit error eps_k; the
+        thresholds are  r = budget / (safety * max eps_1),  r3 = budget / (safety * max eps_2)  (heads without a second rung: r3 from eps_1).  ``flat_index``: a
+        constant image of the batch -- left out of eps, used to place the tap-diversity threshold between it and the other images (geometric mean), or to switch that
+        trigger off where the last tap does not tell them apart (outlier-dominated tokens).  Returns the numbers; the caller installs them (DA2/dpt.py)."""
+        lad = self.ladder
+        if lad is None or "make3" not in lad:
+            raise HipExtError("calibrate: this engine has no precision ladder")
+        B, H, W = x.shape[0], x.shape[-2], x.shape[-1]
+        if self._eng3 is None:
+            self._eng3 = lad["make3"]()
+        eng3 = self._eng3
+        act = self.final_act
+        keep = (self.final_act, eng3.final_act)
+        z2 = None
+        try:
+            self.final_act = eng3.final_act = ACT_NONE
+            z1 = self._forward(x, guide, True)
+            ws = self.workspace(B, H, W, x.device)
+            k_token_diversity(ws.taps[3], ws.taps[3].shape[1], B, ws.ph * ws.pw, self.w.dim, ws.stat_div)
+            dv = ws.stat_div.double().sum(1)
+            tap_div = (dv[:, 0] / dv[:, 1].clamp_min(1e-300)).cpu()
+            if "make" in lad:
+                if self._w_hi is None:
+                    self._w_hi = lad["make"]()
+                ws2 = Workspace(self._w_hi, B, H, W, x.device, head_only=True)
+                ws2.taps = ws.taps
+                if getattr(ws2, "cls_op", None) is not None:
+                    ws2.cls_op = ws.cls_op
+                z2 = self._head(ws2, B, self._w_hi)
+            z3 = eng3._forward(x, guide, True)
+        finally:
+            self.final_act, eng3.final_act = keep
+        use = [i for i in range(B) if i != flat_index]
+        sel = torch.tensor(use, device=x.device)
+
+        def eps(zk):
+            """max over the calibration images and the shift grid of  sum |f(zk + d) - f(z3 + d)| / sum w(z3 + d)  (w: s(1-s) | [z > 0] | 1)"""
+            a, t = zk.index_select(0, sel).flatten(1).double(), z3.index_select(0, sel).flatten(1).double()
+            if act == ACT_NONE:
+                return float((a - t).abs().mean(1).max())
+            worst = 0.0
+            if act == ACT_SIGMOID:      # shifts that put the map's mean at 0.5 ... 0.03
+                shifts = [float(v) for v in torch.linspace(-5.0, 1.0, 13)]
+                centre = -t.median(dim=1, keepdim=True).values
+            else:                       # ReLU: shifts that leave 95 % ... 5 % of the map positive
+                qs = torch.tensor([0.05, 0.2, 0.35, 0.5, 0.65, 0.8, 0.9, 0.95], dtype=t.dtype, device=t.device)
+                shifts, centre = None, -torch.quantile(t, qs, dim=1).t()        # [n, len(qs)]
+            for j in range(len(shifts) if shifts is not None else centre.shape[1]):
+                d = centre + shifts[j] if shifts is not None else centre[:, j:j + 1]
+                if act == ACT_SIGMOID:
+                    fa, ft = torch.sigmoid(a + d), torch.sigmoid(t + d)
+                    wsum = (ft * (1 - ft)).sum(1)
+                else:
+                    fa, ft = (a + d).clamp_min(0), (t + d).clamp_min(0)
+                    wsum = (ft > 0).double().sum(1)
+                worst = max(worst, float(((fa - ft).abs().sum(1) / wsum.clamp_min(1.0)).max()))
+            return worst
+        e1 = eps(z1)
+        res = dict(budget=budget, safety=safety, images=len(use), size=(H, W), eps1=e1, act={ACT_SIGMOID: "sigmoid", ACT_RELU: "relu", ACT_NONE: "none"}[act])
+        if z2 is not None:
+            e2 = eps(z2)
+            r = budget / (safety * max(e1, 1e-30))
+            res.update(eps2=e2, r=min(max(r, 0.02), 0.97), r3=min(max(budget / (safety * max(e2, 1e-30)), min(max(r, 0.02), 0.97)), 0.985))
+        else:
+            res.update(r3=budget / (safety * max(e1, 1e-30)))
+        if flat_index is not None:
+            dmin, dflat = float(tap_div[use].min()), float(tap_div[flat_index])
+            res.update(tap_diversity_images_min=dmin, tap_diversity_flat=dflat, div=math.sqrt(dmin * dflat) if dflat < 0.25 * dmin else 0.0)
+        return res
 
     def _forward(self, x: torch.Tensor, guide: Optional[torch.Tensor], norm: Optional[bool] = None) -> torch.Tensor:
         w = self.w

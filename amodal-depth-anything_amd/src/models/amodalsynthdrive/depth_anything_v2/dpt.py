@@ -214,12 +214,16 @@ def _f8_policy(final_act):
 
 
 _LADDER_F8 = "head"
-# Third rung (round 5; hip_ext.engine.DepthEngine._escalate): r above this -- maps averaging under ~0.1 -- and the image is run again as a whole with every
-# encoder block and the whole head in split precision.  The second rung's own error is 0.8e-3 ... 1.2e-3 of LOGIT error (the encoder's operand rounding), i.e.
-# up to 1.1e-3 in the metric at r = 0.91 (held-out draws of the output-range sweep: ViT-B, constant image, mean 0.03); 1.2e-3 x 0.75 = 9e-4 is where it is handed on.
-_LADDER_R3 = 0.75
-_LADDER_R = {"vitb": 0.42, "vitl": 0.45}
-_LADDER_DIV = 0.10
+# Round 6: the thresholds of the ladder are CALIBRATED per checkpoint on the device (hip_ext.engine.DepthEngine.calibrate, _EngineMixin._calibrate_ladder):
+# round 5 carried them as constants fitted to synthetic weights -- r 0.42 (ViT-B) / 0.45 (ViT-L), third rung 0.75, tap diversity 0.10 -- which a real
+# checkpoint has no reason to share.  The error budget is what is stated instead: a rung is left where its sensitivity-normalised logit error times the
+# image's r reaches _LADDER_BUDGET of the 1e-3 bar.  What is left below are the UNCALIBRATED fallbacks, used only where the calibration cannot run (the
+# first forward arrives inside a caller's stream capture) or is switched off (ADA_LADDER_CALIBRATE=0): one conservative set for every encoder.
+_LADDER_BUDGET = float(_os.environ.get("ADA_LADDER_BUDGET", "8e-4"))
+_LADDER_SAFETY = 1.1          # on the largest eps the calibration images show
+_LADDER_FALLBACK = dict(r=0.40, r3=0.75, div=0.10)
+_LADDER_CALIBRATE = _os.environ.get("ADA_LADDER_CALIBRATE", "1") != "0"
+_LADDER_CAL_SIZE = tuple(int(v) for v in _os.environ.get("ADA_LADDER_CAL_SIZE", "266x322").split("x"))
 _LADDER_DIV_IN = 1e-4      # variance of the patchified input over the image's patches / their mean square: 0 for constant images and pixel checkerboards, ~0.25-1 otherwise
 # What the second rung re-runs in split precision: the whole head -- on ViT-L without the ResidualConvUnit convolutions of the two finest levels (the four
 # 148^2 and four 74^2 convs: 23 % of the rung's MACs): on the five low-mean / constant ViT-L fixtures that subset is as good or better (5.8-6.5e-4 against
@@ -238,19 +242,19 @@ def _ladder_threshold(module, encoder, final_act, mode):
         val = 0.0 if val.lower() in ("off", "0", "false", "") else float(val)
     if val is False:
         val = 0.0
-    if final_act != "sigmoid" or mode != "auto" or _os.environ.get("ADA_HEAD_SPLIT") is not None:
+    if final_act != "sigmoid" or encoder == "vits" or mode != "auto" or _os.environ.get("ADA_HEAD_SPLIT") is not None:
         return None
     if val is None or val is True:
-        val = _LADDER_R.get(encoder)
+        val = _LADDER_FALLBACK["r"]       # provisional: replaced by the calibrated threshold (_calibrate_ladder) unless the caller named one
     return float(val) if val else None
 
 
 def _flat_input_rung(module, final_act, mode):
-    """The heads WITHOUT a sigmoid (raw ReLU, 'ssi') keep one rung of the ladder: an image whose patch tokens are all alike (constant / checkerboard input: every
+    """The models WITHOUT a second rung (raw ReLU, 'ssi', and -- round 6 -- sigmoid ViT-S, whose whole head is in split precision already) keep one rung of the ladder: an image whose patch tokens are all alike (constant / checkerboard input: every
     patch of the patchified input the same: _LADDER_DIV_IN) is run again with every encoder block and the whole head in split precision -- its rounding errors add
     coherently over positions and nothing compresses them: raw ViT-B on an all-zero 518 x 518 image 1.15e-3 -> 4.7e-4, 'ssi' ViT-B 1.13e-3 -> 4.4e-4, raw ViT-L on
     a checkerboard 1.14e-3 -> 3.9e-4 (profiles/r05_aa_*).  Off with precision_ladder = False / ADA_LADDER_R = off, or when the caller chose a precision."""
-    if final_act == "sigmoid" or mode != "auto" or _os.environ.get("ADA_HEAD_SPLIT") is not None or getattr(module, "encoder_precision", "auto") != "auto":
+    if mode != "auto" or _os.environ.get("ADA_HEAD_SPLIT") is not None or getattr(module, "encoder_precision", "auto") != "auto":
         return False
     val = getattr(module, "precision_ladder", None)
     if val is None:
@@ -263,24 +267,33 @@ def _flat_input_rung(module, final_act, mode):
 class _EngineMixin:
     """Lazily builds / refreshes the packed weights + launch plan whenever a parameter changes."""
 
-    _RESCAN_EVERY = 32    # calls between two full walks of the module tree (safety net for Parameter objects replaced by attribute assignment)
-
     def _param_tensors(self, rescan=False):
         """The parameter / buffer tensors whose (storage address, version counter) pairs stamp the packed weights.  Walking ``state_dict()`` on every
-        call cost 0.7-1.0 ms for ViT-L's 425 keys -- 18 % of the single-image latency; the list is cached and rebuilt by the hooks that can replace
-        tensors (``_apply``: .cuda() / .to() / .half(); ``load_state_dict``), and re-walked every _RESCAN_EVERY calls as a safety net for a Parameter
-        object replaced by plain attribute assignment on a sub-module (call ``invalidate_engine()`` after doing that to take effect at once)."""
+        call cost 0.7-1.0 ms for ViT-L's 425 keys -- 18 % of the single-image latency; the list is cached together with the SLOT every tensor sits in
+        (the owning sub-module's ``_parameters`` / ``_buffers`` dict and its key) and each call checks that every slot still holds the very object that
+        was stamped: a Parameter replaced by attribute assignment on a sub-module, ``load_state_dict(..., assign=True)`` on a child, parametrize / pruning
+        utilities all show up at once (round 5 re-walked the tree only every 32 calls: up to 31 forwards on the old weights).  ~20 us for ViT-L."""
         lst = self.__dict__.get("_engine_plist")
-        n = self.__dict__.get("_engine_calls", 0) + 1
-        object.__setattr__(self, "_engine_calls", n)
-        if lst is None or rescan or n % self._RESCAN_EVERY == 0:
-            items = list(self.state_dict(keep_vars=True).items())
-            object.__setattr__(self, "_engine_pnames", [k for k, _ in items])
-            lst = [v for _, v in items]
+        if lst is not None and not rescan:
+            for (d, k), t in zip(self.__dict__["_engine_pslots"], lst):
+                if d.get(k) is not t:
+                    lst = None
+                    break
+        if lst is None or rescan:
+            slots, names = [], []
+            for mname, mod in self.named_modules():      # the traversal order of state_dict(): a module's parameters, its persistent buffers, then its children
+                for d, skip in ((mod._parameters, ()), (mod._buffers, mod._non_persistent_buffers_set)):
+                    for k, v in d.items():
+                        if v is not None and k not in skip:
+                            slots.append((d, k))
+                            names.append(f"{mname}.{k}" if mname else k)
+            if names != list(self.state_dict(keep_vars=True).keys()):     # a module with a custom state_dict: fall back to stamping its state_dict (no slots)
+                items = list(self.state_dict(keep_vars=True).items())
+                names, slots = [k for k, _ in items], [({i: v}, i) for i, (_, v) in enumerate(items)]
+            lst = [d[k] for d, k in slots]
+            object.__setattr__(self, "_engine_pnames", names)
+            object.__setattr__(self, "_engine_pslots", slots)
             object.__setattr__(self, "_engine_plist", lst)
-            if not self.__dict__.get("_engine_hooked"):
-                object.__setattr__(self, "_engine_hooked", True)
-                self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_engine())
         return lst
 
     def invalidate_engine(self):
@@ -338,8 +351,8 @@ class _EngineMixin:
 
                 def third():
                     return DepthEngine(PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=every, enc_split_blocks=depth, f8=f8_user or "both"), final_act, norm_in)
-                ladder = dict(r=ladder_r, div=_LADDER_DIV, make=lambda: PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=groups, head_only=True, f8=ladder_f8),
-                              r3=max(_LADDER_R3, ladder_r), make3=third)
+                ladder = dict(r=ladder_r, div=_LADDER_FALLBACK["div"], div_in=_LADDER_DIV_IN, make=lambda: PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=groups, head_only=True, f8=ladder_f8),
+                              r3=max(_LADDER_FALLBACK["r3"], ladder_r), make3=third)
             if ladder is None and _flat_input_rung(self, self.depth_head.final_act, mode):
                 final_act, norm_in, depth, encoder, f8_ = self.depth_head.final_act, bool(getattr(self, "normalise_input", False)), len(self.pretrained.blocks), self.encoder, f8
 
@@ -347,10 +360,55 @@ class _EngineMixin:
                     return DepthEngine(PackedWeights(sd, encoder, guided=guided, amodal_head=amodal_head, split_head=tuple(g for g in HEAD_GROUPS if g != "projw"),
                                                      enc_split_blocks=depth, f8=f8_), final_act, norm_in)
                 # (input-side trigger only: the raw models' last tap does not tell -- synthetic raw ViT-G reads a token diversity of 0.09 on a small NOISE image)
+                # round 6: + the r trigger (sum of the metric's weights / sum |out|, hip_ext.engine._escalate) with a CALIBRATED threshold -- the un-centred raw maps of
+                # profiles/r05_ac_* (mostly clipped, the rest just above the kink) read up to 1.1e-3 under the default policy and 6.6e-4 with everything split
                 ladder = dict(div_in=_LADDER_DIV_IN, make3=everything)
-            object.__setattr__(self, "_engine_obj", DepthEngine(pw, self.depth_head.final_act, bool(getattr(self, "normalise_input", False)), ladder=ladder))
+            eng = DepthEngine(pw, self.depth_head.final_act, bool(getattr(self, "normalise_input", False)), ladder=ladder)
+            object.__setattr__(self, "_engine_obj", eng)
             object.__setattr__(self, "_engine_stamp", stamp)
+            if ladder is not None:
+                self._calibrate_ladder(eng, plist, explicit_r=getattr(self, "precision_ladder", None) not in (None, True) or _os.environ.get("ADA_LADDER_R") is not None)
         return self._engine_obj
+
+    def _calibrate_ladder(self, eng, plist, explicit_r=False):
+        """Installs the calibrated thresholds (hip_ext.engine.DepthEngine.calibrate) into the engine's ladder and exposes the numbers as
+        ``module.ladder_calibration``.  Calibration set: two noise and two image-like synthetic inputs (src/util/synth_weights.make_inputs; the guide tensor takes
+        the trailing channels of [rgb | mask | observation], whatever the guide_type) plus one all-zero image that places the tap-diversity threshold, at
+        _LADDER_CAL_SIZE.  Cached by the stamp of every parameter BUT the final 1x1 bias (the logit error does not depend on it -- the bias is added in fp32 -- and
+        callers that sweep the operating point rewrite exactly that tensor).  A threshold the caller named (module.precision_ladder = <float> / ADA_LADDER_R)
+        is kept; the third rung and the diversity trigger are calibrated all the same."""
+        import torch as _torch
+        lad = eng.ladder
+        if not _LADDER_CALIBRATE or "make3" not in lad or not plist[0].is_cuda or _torch.cuda.is_current_stream_capturing():     # (CPU parameters: the forward itself refuses)
+            object.__setattr__(self, "ladder_calibration", None)
+            return
+        skip = "depth_head.scratch.output_conv2.2.bias"
+        key = tuple((v.data_ptr(), v._version) for n, v in zip(self._engine_pnames, plist) if n != skip) + (getattr(self, "f8_terms", None), _LADDER_BUDGET, _LADDER_CAL_SIZE)
+        cal = self.__dict__.get("_ladder_cal")
+        if cal is None or cal[0] != key:
+            from src.util.synth_weights import make_inputs
+            dev = plist[0].device
+            H, W = _LADDER_CAL_SIZE
+            parts = [make_inputs(2, H, W, seed=9001, device=dev, style="noise"), make_inputs(2, H, W, seed=9002, device=dev, style="structured"),
+                     make_inputs(1, H, W, seed=0, device=dev, style="zeros")]
+            x = _torch.cat([p[0] for p in parts], 0)
+            guide = None
+            cg = eng.w.guide_channels if eng.w.guided else 0
+            if cg:
+                guide = _torch.cat([_torch.cat([p[1], p[2], p[3]], 1) for p in parts], 0)[:, 5 - cg:].contiguous()
+            cal = (key, eng.calibrate(x, guide, budget=_LADDER_BUDGET, safety=_LADDER_SAFETY, flat_index=x.shape[0] - 1))
+            object.__setattr__(self, "_ladder_cal", cal)
+        res = dict(cal[1])
+        if "r" in lad and not explicit_r and "r" in res:
+            lad["r"] = res["r"]
+        if "r" in lad:
+            lad["r3"] = max(res["r3"], lad["r"]) if "eps2" in res else lad["r3"]
+        else:
+            lad["r3"] = res["r3"]
+        if "div" in lad and "div" in res:
+            lad["div"] = res["div"]
+        res.update(r_installed=lad.get("r"), r3_installed=lad.get("r3"), div_installed=lad.get("div"))
+        object.__setattr__(self, "ladder_calibration", res)
 
     def _run(self, x, guide, normalise=None):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):

@@ -348,8 +348,12 @@ int ada_blend_fwd(const float* amodal, const float* base, const float* mask, int
 /* Per-image moments of a sigmoid-head depth map (output of nn.Sigmoid(), reference DA2/dpt.py:146-151): sums[(b * chunks + c) * 2 + {0, 1}] =
  * (sum s, sum s (1 - s)) over chunk c of image b; the caller adds the chunk sums (fixed order, no atomics: bit-reproducible).  sum s(1-s) / sum s
  * is the factor by which the sigmoid compresses the head's logit error in mean|a - b| / mean|b| for this image: hip_ext/engine.py's precision
- * ladder re-runs the DPT head in split precision for the images where it is large (depth maps concentrated near 0).  No reference counterpart. */
-int ada_depth_stats_fwd(const float* in, int32_t batch, int64_t n_per_image, int32_t chunks, float* sums, void* stream);
+ * ladder re-runs the DPT head in split precision for the images where it is large (depth maps concentrated near 0).  No reference counterpart.
+ * ABI 8: `act` (ADA_ACT_*) names the final activation of the head and with it the pair that plays this role -- the sensitivity of the metric to a logit
+ * error of mean size eps is eps * sums[1] / sums[0]:  SIGMOID (sum s, sum s (1 - s));  RELU (sum out, number of positive outputs) -- a clipped pixel
+ * carries no error, and a map that is mostly clipped with the rest just above the kink has a small denominator (RAW/dpt.py:109-115,182-184);  NONE
+ * ('ssi' logits: sum |out|, number of outputs). */
+int ada_depth_stats_fwd(const float* in, int32_t batch, int64_t n_per_image, int32_t chunks, int32_t act, float* sums, void* stream);
 /* Token diversity of an encoder tap (operand-typed [batch * rows_per_image, ld], the first `dim` columns of a row): for image b and column chunk j
  * (64 columns; ceil(dim / 64) chunks)  sums[(b * chunks + j) * 2 + {0, 1}] = (sum over the chunk's columns of Var_rows, sum of E_rows[t^2]).  The caller adds the
  * chunks; sum Var / sum E[t^2] ~ 0.02 marks inputs whose patch tokens are all alike (constant images), where the head's operand rounding errors add

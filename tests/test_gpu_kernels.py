@@ -302,6 +302,17 @@ def test_depth_stats_per_image_moments(hip, B, H, W):
     again = torch.empty_like(sums)
     hip.depth_stats(s_, again)
     assert torch.equal(sums, again)       # no atomics: bit-reproducible
+    # the pairs of the heads without a sigmoid (ABI 8): ReLU (sum out, number of positive outputs), none (sum |out|, number of outputs)
+    z = (s_ - 0.7) * 3.0
+    zr = z.clamp_min(0)
+    hip.depth_stats(zr, sums, hip.ACT_RELU)
+    got = sums.cpu().double().sum(1)
+    ref = torch.stack([zr.cpu().double().flatten(1).sum(1), (zr.cpu() > 0).double().flatten(1).sum(1)], dim=1)
+    assert torch.allclose(got, ref, rtol=2e-6), (got, ref)
+    hip.depth_stats(z, sums, hip.ACT_NONE)
+    got = sums.cpu().double().sum(1)
+    ref = torch.stack([z.cpu().double().abs().flatten(1).sum(1), torch.full((B,), float(H * W), dtype=torch.float64)], dim=1)
+    assert torch.allclose(got, ref, rtol=2e-6), (got, ref)
 
 
 @pytest.mark.parametrize("B,Np,D,ld", [(2, 1369, 768, 768), (3, 99, 1024, 2048), (1, 1, 384, 384), (2, 37, 100, 128)])

@@ -128,3 +128,25 @@ def test_encoder_precision_policy_table(monkeypatch):
     assert _encoder_split_policy(5, "vitl", "sigmoid") == 5
     monkeypatch.setenv("ADA_ENC_SPLIT", "3")
     assert _encoder_split_policy("auto", "vitl", "sigmoid") == 3 and _encoder_split_policy(0, "vitl", "none") == 0
+
+
+def test_engine_stamp_sees_a_parameter_replaced_on_a_sub_module():
+    """The packed weights are stamped by the parameter tensors' (address, version) pairs taken from a cached list; every call checks that each slot
+    of the module tree still holds the object that was stamped, so a Parameter REPLACED on a sub-module (attribute assignment, load_state_dict with
+    assign=True on a child, pruning utilities) is picked up by the very next forward -- round 5 noticed it only at its next periodic re-walk."""
+    m = get_model("AmodalDAv2", guide_type="mask", loss_stategy="x", encoder="vits", pretrained=False).eval()
+    enc = m.encoder
+    first = enc._param_tensors()
+    assert enc._engine_pnames == list(enc.state_dict().keys()) and all(a is b for a, b in zip(first, enc.state_dict(keep_vars=True).values()))
+    assert enc._param_tensors() is first            # nothing changed: the cached list itself
+    blk = enc.pretrained.blocks[3]
+    old = blk.attn.proj.weight
+    blk.attn.proj.weight = torch.nn.Parameter(old.detach().clone() * 2)
+    second = enc._param_tensors()
+    i = enc._engine_pnames.index("pretrained.blocks.3.attn.proj.weight")
+    assert second is not first and second[i] is blk.attn.proj.weight and first[i] is old
+    sd = {k: v.clone() + 1 for k, v in enc.depth_head.state_dict().items()}
+    enc.depth_head.load_state_dict(sd, assign=True)       # replaces every Parameter object of the child
+    third = enc._param_tensors()
+    j = enc._engine_pnames.index("depth_head.scratch.output_conv2.2.bias")
+    assert third[j] is enc.depth_head.scratch.output_conv2[2].bias and third[j] is not second[j]

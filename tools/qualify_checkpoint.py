@@ -31,7 +31,7 @@ def load_weights(path):
     if path.endswith(".safetensors"):
         from safetensors.torch import load_file
         return load_file(path)
-    sd = torch.load(path, map_location="cpu")
+    sd = torch.load(path, map_location="cpu", weights_only=True)
     return sd.get("state_dict", sd) if isinstance(sd, dict) else sd
 
 

@@ -1,12 +1,15 @@
 #!/bin/bash
-# round-5 closing profiles: full GPU suite (durations), parity of every fixture, bench with default flags (live PMC traffic), rocprofv3 kernel trace of the bench
-# command, PMC traffic passes (the committed, digest-stamped fallback), SQ counters, per-shape table, configs 2 / 5 (+ kernel trace of config 2)
+# The closing profiles of a round -- ROUND=6 gpurun -- 'ROUND=6 bash tools/sessions/closing.sh' writes gpurun_out/r${ROUND}z/, whose summaries are copied to
+# profiles/r0${ROUND}_z_*: full GPU suite (durations), parity of every fixture, bench with default flags (live PMC traffic), rocprofv3 kernel trace of the bench
+# command, PMC traffic passes (the committed, digest-stamped fallback), SQ counters, per-shape table, configs 2 / 5 (+ kernel trace of config 2).
+# (Rounds 2-5 each had their own copy of this script plus one script per experiment session: 46 files by round 5; they are in the history up to 67edbad.)
 cd "$GRAFT_REPO_ROOT" || exit 1
+ROUND=${ROUND:-6}
 export TMPDIR=/tmp
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-export ADA_COLLECTED="round 5, $(date -u +%Y-%m-%dT%H:%MZ)"
-mkdir -p gpurun_out/r5z
-O=$PWD/gpurun_out/r5z
+export ADA_COLLECTED="round $ROUND, $(date -u +%Y-%m-%dT%H:%MZ)"
+mkdir -p gpurun_out/r${ROUND}z
+O=$PWD/gpurun_out/r${ROUND}z
 R=$PWD
 ( time timeout 1800 python -m pytest tests -m gpu -q --durations=0 -p no:cacheprovider 2>&1 | grep -v amdgpu | tail -n 700 ) > $O/gpu_suite.txt 2>&1; tail -n 6 $O/gpu_suite.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu | tail -n 2

@@ -659,7 +659,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 && 
                         gt.y = silu(x1.y + b1.y) * (x2.y + b2.y);
                         gt.z = silu(x1.z + b1.z) * (x2.z + b2.z);
                         gt.w = silu(x1.w + b1.w) * (x2.w + b2.w);
-                        *(opx4*)(p.out_op + (long)m * p.ldo_op + nh) = pack4(gt);
+                        // (split forms, round 6: the gated hidden feeds mlp.w3 -- swiglu_ffn.py:33 -- and exists in the operand type only; in a split-precision block it
+                        //  is written [hi | lo] / [hi | lo8 | hi8] like every other split activation.  Never in the generated 4-wave loop's kernel: use_pipe4)
+                        if constexpr (PIPE4) *(opx4*)(p.out_op + (long)m * p.ldo_op + nh) = pack4(gt);
+                        else store_op4(p, p.out_op + (long)m * p.ldo_op + nh, nh, gt);
                     }
                 }
             }
@@ -1107,6 +1110,7 @@ static inline double tile_time_cu(long M, long N, long K, int bm, int bn, double
 // (its scalar A-offset counters assume a monotonic walk: a split operand, whose third k segment re-reads the first, stays on the 8-wave loop)
 static inline bool use_pipe4(const IgemmDev& d) {
     if (d.a_dup_seg != 0 || d.a_wrap != 0 || d.f8_from != 0 || d.tap_cols != 0) return false;
+    if ((d.flags & ADA_EP_SWIGLU) && d.split_seg != 0) return false;     // the SwiGLU epilogue of the 4-wave kernel writes the plain form only
     if (d.variant != 0) return d.variant >= 16;
     if (d.K >= 8192) return true;
     // With a cheap operand-typed epilogue (bias, SwiGLU: no fp32 output, no residual / LayerScale / GELU / row statistics) the slower epilogue of the
@@ -1254,12 +1258,12 @@ extern "C" int ada_igemm(const ada_igemm_args* a, void* stream) {
     }
     const int split_abs = a->split_seg < 0 ? -a->split_seg : a->split_seg;   // < 0: the [hi | lo8 | hi8] form
     if (a->split_seg != 0) {
-        ADA_REQUIRE(a->out_op && split_abs % 8 == 0 && !swiglu, ADA_EINVAL, "ada_igemm: split_seg needs out_op, a multiple of 8, no SwiGLU");
+        ADA_REQUIRE(a->out_op && split_abs % 8 == 0, ADA_EINVAL, "ada_igemm: split_seg needs out_op and a multiple of 8");
         // (behind a shuffle only the 8-column operand-only epilogue writes the [hi | lo8 | hi8] form: its conditions are required here, or the 4-column
         //  path -- compiled without the fp8 form for EPI_SHUFFLE -- would write [hi | lo] where the consumer reads bytes)
         ADA_REQUIRE(a->split_seg > 0 || !shuffle || (a->shuffle_c % 8 == 0 && !(f & ADA_EP_RESIDUAL) && a->ldo_op % 8 == 0), ADA_EUNSUPPORTED,
                     "ada_igemm: the fp8 form of a split output (split_seg < 0) behind MAP_SHUFFLE needs shuffle_c %% 8 == 0, ldo_op %% 8 == 0 and no residual");
-        const int cols = shuffle ? a->shuffle_c : a->N;
+        const int cols = shuffle ? a->shuffle_c : swiglu ? a->N / 2 : a->N;
         ADA_REQUIRE(cols <= split_abs && a->ldo_op >= 2L * split_abs, ADA_EINVAL, "ada_igemm: split_seg=%d too small for %d columns / ldo_op=%ld", a->split_seg, cols, (long)a->ldo_op);
     }
     if (a->bias_row_mod != 0) {

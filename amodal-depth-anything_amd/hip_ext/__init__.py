@@ -26,7 +26,7 @@ EP_BIAS, EP_GELU, EP_GAMMA, EP_RESIDUAL, EP_RELU_OP, EP_SWIGLU, EP_TAIL, EP_RELU
 ACT_NONE, ACT_SIGMOID, ACT_RELU = 0, 1, 2
 
 EXPORTS = (
-    "ada_abi_version", "ada_operand_dtype", "ada_last_error", "ada_igemm", "ada_attention_fwd",
+    "ada_abi_version", "ada_operand_dtype", "ada_last_error", "ada_igemm", "ada_attention_fwd", "ada_attention_ex",
     "ada_pos_embed_resize", "ada_layernorm_fwd", "ada_layernorm_ex", "ada_patchify", "ada_write_cls", "ada_bilinear_fwd", "ada_selftest",
     "ada_minmax_fwd", "ada_depth_stats_fwd", "ada_token_diversity_fwd", "ada_normalize_fwd", "ada_blend_fwd", "ada_depth_eval_fwd", "ada_tile_blend_fwd", "ada_dpt_tail_fwd", "ada_tapsum_resize_fwd",
     "ada_debug_set_tile", "ada_debug_set_variant", "ada_debug_set_group", "ada_debug_last_tile",
@@ -107,6 +107,8 @@ def load(path: Optional[str] = None):
     lib.ada_pos_embed_resize.restype = c_int
     lib.ada_attention_fwd.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]
     lib.ada_attention_fwd.restype = c_int
+    lib.ada_attention_ex.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_void_p]
+    lib.ada_attention_ex.restype = c_int
     lib.ada_layernorm_fwd.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_float,
                                       c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p]
     lib.ada_layernorm_fwd.restype = c_int
@@ -261,11 +263,15 @@ def igemm(*, M, N, K, A, lda, W, k_alg=None, a_mode=A_PLAIN, conv=None, bias=Non
         _tile_log.append((M, N, K, load().ada_debug_last_tile()))
 
 
-def attention(qkv: torch.Tensor, out: torch.Tensor, batch: int, n_tokens: int, heads: int):
+def attention(qkv: torch.Tensor, out: torch.Tensor, batch: int, n_tokens: int, heads: int, ld_out: int = 0, split_seg: int = 0):
+    """ada_attention_fwd / ada_attention_ex: ``ld_out`` = row stride of ``out`` (0: heads * 64), ``split_seg`` != 0: the split-precision forms of the output row."""
     op = operand_dtype()
     ev = _timer.start() if (_timer is not None and _timer.active) else None
-    _check(load().ada_attention_fwd(_dev(qkv, "qkv", op), _dev(out, "out", op), batch, n_tokens, heads, _stream()),
-           "ada_attention_fwd")
+    if ld_out or split_seg:
+        _check(load().ada_attention_ex(_dev(qkv, "qkv", op), _dev(out, "out", op), batch, n_tokens, heads, ld_out, split_seg, _stream()), "ada_attention_ex")
+    else:
+        _check(load().ada_attention_fwd(_dev(qkv, "qkv", op), _dev(out, "out", op), batch, n_tokens, heads, _stream()),
+               "ada_attention_fwd")
     if ev is not None:
         _timer.stop("attention", ev, 4.0 * batch * heads * 64 * float(n_tokens) ** 2)  # QK^T + PV, MAC = 2
 

@@ -184,8 +184,10 @@ class PackedWeights:
         # early is amplified by every later block (oracle study, profiles/r04_e_raw_vitg_operand_noise_by_block.txt: blocks 0-9 of ViT-G carry
         # half of the encoder's share, blocks 30-39 a fiftieth), so for the unbounded-output ViT-G model, whose encoder alone reaches
         # 0.7e-3 ... 1.05e-3 depending on the weight draw, the head's split precision is not enough.  qkv and fc1 / w12 read the LayerNorm
-        # output as [hi | lo] (full three-term product); proj and fc2 / w3 read activations that exist in the operand type only (attention
-        # output, MLP hidden) against [w_hi | w_lo] weights (ada_igemm_args.a_wrap: the weight's rounding error goes, the activation's stays).
+        # output as [hi | lo] (full three-term product).  Round 6: so do proj and fc2 / w3 -- the attention kernel and the GELU / SwiGLU epilogues write
+        # the attention output and the MLP hidden of a split block in the split form too (rounds 4-5 walked the plain activation twice against
+        # [w_hi | w_lo]: the weight's rounding error went, the activation's stayed -- and that was what bounded the everything-split engine: raw ViT-G
+        # 6.2e-4 of output error from these two activations alone against 2.9e-4 from the attention core, oracle/study_rung3_floor.py).
         self.enc_split_blocks = max(0, min(int(enc_split_blocks), cfg["depth"]))
         # ... with the two correction terms of qkv / fc1 / w12 on the fp8 matrix pipe where the build has it (fp16 operands, D a multiple of 128)
         # f8: which of the two users take it -- "both" | "enc" | "head" | "none" (the caller's precision policy, DA2/dpt.py::_f8_policy)
@@ -272,22 +274,18 @@ class PackedWeights:
                 hi_ = wm.to(op)
                 return torch.cat([hi_, hi_, (wm - hi_.float()).to(op)], dim=1).contiguous(), 0
 
-            def lin2(wm):   # [N, K] -> [w_hi | w_lo] (against a plain activation walked twice, a_wrap)
-                if not esplit:
-                    return lin(wm)
-                hi_ = wm.to(op)
-                return torch.cat([hi_, (wm - hi_.float()).to(op)], dim=1).contiguous()
             qkv_w, qkv_f8 = lin3(qw)
+            proj_w, proj_f8 = lin3(f32(b + "attn.proj.weight"))
             blk = dict(
                 ln1_w=f32(b + "norm1.weight"), ln1_b=f32(b + "norm1.bias"), esplit=esplit,
                 qkv_w=qkv_w, qkv_f8=qkv_f8, qkv_b=qb,
-                proj_w=lin2(f32(b + "attn.proj.weight")), proj_b=f32(b + "attn.proj.bias"), ls1=f32(b + "ls1.gamma"),
+                proj_w=proj_w, proj_f8=proj_f8, proj_b=f32(b + "attn.proj.bias"), ls1=f32(b + "ls1.gamma"),
                 ln2_w=f32(b + "norm2.weight"), ln2_b=f32(b + "norm2.bias"), ls2=f32(b + "ls2.gamma"),
             )
             if self.ffn == "mlp":
                 fc1_w, fc1_f8 = lin3(f32(b + "mlp.fc1.weight"))
-                blk.update(fc1_w=fc1_w, fc1_f8=fc1_f8, fc1_b=f32(b + "mlp.fc1.bias"),
-                           fc2_w=lin2(f32(b + "mlp.fc2.weight")), fc2_b=f32(b + "mlp.fc2.bias"))
+                fc2_w, fc2_f8 = lin3(f32(b + "mlp.fc2.weight"))
+                blk.update(fc1_w=fc1_w, fc1_f8=fc1_f8, fc1_b=f32(b + "mlp.fc1.bias"), fc2_w=fc2_w, fc2_f8=fc2_f8, fc2_b=f32(b + "mlp.fc2.bias"))
                 blk["hidden"] = blk["fc1_w"].shape[0]
             else:
                 w12, b12 = f32(b + "mlp.w12.weight"), f32(b + "mlp.w12.bias")
@@ -297,8 +295,8 @@ class PackedWeights:
                 idx = torch.arange(hid, device=w12.device).reshape(-1, 32)
                 order = torch.stack([idx, idx + hid], dim=1).reshape(-1)
                 w12_w, w12_f8 = lin3(w12[order])
-                blk.update(w12_w=w12_w, w12_f8=w12_f8, w12_b=b12[order].contiguous(),
-                           w3_w=lin2(f32(b + "mlp.w3.weight")), w3_b=f32(b + "mlp.w3.bias"))
+                w3_w, w3_f8 = lin3(f32(b + "mlp.w3.weight"))
+                blk.update(w12_w=w12_w, w12_f8=w12_f8, w12_b=b12[order].contiguous(), w3_w=w3_w, w3_f8=w3_f8, w3_b=f32(b + "mlp.w3.bias"))
                 blk["hidden"] = hid
             self.blocks.append(blk)
         self.norm_w, self.norm_b = f32(p + "norm.weight"), f32(p + "norm.bias")
@@ -488,9 +486,10 @@ class Workspace:
             # LayerNorm output ([hi | lo] column segments for the split-precision blocks: PackedWeights.enc_split_blocks)
             self.y = z(T, 2 * D if pw_.enc_split_blocks > 0 else D)
             self.qkv = z(T, 3 * D)
-            self.o = z(T, D)
+            wide = 2 if pw_.enc_split_blocks > 0 else 1       # attention output / MLP hidden: [hi | lo] / [hi | lo8 | hi8] rows in the split blocks
+            self.o = z(T, wide * D)
             hidden = pw_.blocks[0]["hidden"]
-            self.hd = z(T, hidden)
+            self.hd = z(T, wide * hidden)
         self.taps = [z(P, m * D) for _ in range(4)]
         # the precision ladder's per-image statistics, one buffer (one host read): stat_sums = (sum s, sum s (1 - s)) of the depth map in chunks
         # (ada_depth_stats_fwd), stat_div = (sum of column variances, sum of column mean squares) of the last tap in 64-column chunks (ada_token_diversity_fwd)
@@ -558,6 +557,13 @@ class Workspace:
         self.fin = None if self.fused_tail else z(B, H + 2, W + 2, mm("oc2") * self.halfp)
 
 
+# Head branches on side streams (round 6): the four reassemble -> input_projection -> layerN_rn chains (DA2/dpt.py:161-187) and the
+# ResidualConvUnit 1 of levels 0-2 (util/blocks.py:131-133) are independent of each other until the refinenets join them; at small batches their launches
+# fill 0.04-0.7 of a round of the 256 CUs (profiles/r05_e_config2_shapes.txt), so below HEAD_STREAMS_ROWS patch rows they are issued on four HIP streams
+# (fork / join with events: capturable into the forward's graph) and the coarse levels run in the CUs the fine level leaves idle.  Same kernels, same
+# arguments, same bits.  ADA_HEAD_STREAMS=0 / 1: never / always.
+HEAD_STREAMS = os.environ.get("ADA_HEAD_STREAMS", "auto")
+HEAD_STREAMS_ROWS = int(os.environ.get("ADA_HEAD_STREAMS_ROWS", str(12 * 1369)))
 GRAPH_MODE = os.environ.get("ADA_GRAPH", "auto")
 # "auto": graph replay for calls of up to one 518x518 image.  Measured (profiles/r02_k_hip_graph_latency_ab.txt): the forward is device-bound
 # from ViT-B upwards (replay == launches within 0.5 % at B = 1..8) and host-bound only for a single ViT-S image (3.55 -> 2.62 ms).
@@ -636,6 +642,7 @@ class DepthEngine:
         self._ws: "OrderedDict[tuple, Workspace]" = OrderedDict()
         self._graphs: "OrderedDict[tuple, object]" = OrderedDict()   # key -> _GraphedForward | False (capture refused) | int (sightings)
         self._lock = threading.Lock()
+        self._streams: Dict[str, list] = {}      # device -> the three side streams of the head's forked section
 
     def max_batch(self, H: int, W: int) -> int:
         if H * W > MAX_ROWS:
@@ -654,6 +661,13 @@ class DepthEngine:
         else:
             self._ws.move_to_end(key)
         return ws
+
+    def _side_streams(self, device):
+        key = str(device)
+        st = self._streams.get(key)
+        if st is None:
+            st = self._streams[key] = [torch.cuda.Stream(device=device) for _ in range(3)]
+        return st
 
     def saturation_report(self, x: torch.Tensor, guide: Optional[torch.Tensor]):
         """Diagnostic forward, not the hot path: runs ``_forward`` with a probe behind every launch that writes an operand-typed tensor and
@@ -866,14 +880,17 @@ class DepthEngine:
         self.escalated += Be
         return out
 
-    def calibrate(self, x: torch.Tensor, guide: Optional[torch.Tensor], budget: float = 8e-4, safety: float = 1.1, flat_index: Optional[int] = None) -> dict:
+    def calibrate(self, x: torch.Tensor, guide: Optional[torch.Tensor], budget: float = 9e-4, safety: float = 1.1, flat_index: Optional[int] = None,
+                  rule: str = "cross") -> dict:
         """Self-calibration of the ladder's thresholds for THIS checkpoint, on the device, with no oracle (round 6; round 5's thresholds were ~12 constants fitted
         to synthetic weights).  The calibration images ``x`` ([0, 1] RGB; ``guide`` with the model's guide channels) run through the first rung, through the second
         (head re-run from the first rung's taps, where the policy has one) and through the third-rung engine -- every encoder block and the whole head in split
         precision, 1.6-3.7e-4 from the reference where it was measured -- with the final activation switched OFF, i.e. as logits z1, z2, z3.  For a grid of bias
         shifts d (the final bias is added in fp32: moving it moves the map's operating point and nothing else) the metric of rung k against the third,
-        mean|f(z_k + d) - f(z_3 + d)| / mean f(z_3 + d), divided by the image's r (see _escalate) is the rung's sensitivity-normalised logit error eps_k; the
-        thresholds are  r = budget / (safety * max eps_1),  r3 = budget / (safety * max eps_2)  (heads without a second rung: r3 from eps_1).  ``flat_index``: a
+        e = mean|f(z_k + d) - f(z_3 + d)| / mean f(z_3 + d), is known together with the image's r (see _escalate); e / r is the rung's sensitivity-normalised
+        logit error eps_k.  Rule "cross" (default): a rung is left at the smallest r at which any calibration point has safety * e > budget; rule "global":
+        at budget / (safety * max eps_k) -- the worst eps anywhere on the grid (round 5's hand-fitted constants, 0.42 / 0.45, are what "global" returns for the
+        synthetic fills they were fitted on at budget 9e-4).  r from rung 1, r3 from rung 2 (heads without a second rung: r3 from rung 1).  ``flat_index``: a
         constant image of the batch -- left out of eps, used to place the tap-diversity threshold between it and the other images (geometric mean), or to switch that
         trigger off where the last tap does not tell them apart (outlier-dominated tokens).  Returns the numbers; the caller installs them (DA2/dpt.py)."""
         lad = self.ladder
@@ -907,36 +924,51 @@ class DepthEngine:
         use = [i for i in range(B) if i != flat_index]
         sel = torch.tensor(use, device=x.device)
 
-        def eps(zk):
-            """max over the calibration images and the shift grid of  sum |f(zk + d) - f(z3 + d)| / sum w(z3 + d)  (w: s(1-s) | [z > 0] | 1)"""
+        def curve(zk):
+            """For every calibration image and every shift d of the grid: (r, e) = (the image's sensitivity sum w(z3 + d) / sum |f(z3 + d)|, the metric
+            sum |f(zk + d) - f(z3 + d)| / sum |f(z3 + d)| of rung k against the third) -- w: s(1-s) | [z > 0] | 1."""
             a, t = zk.index_select(0, sel).flatten(1).double(), z3.index_select(0, sel).flatten(1).double()
-            if act == ACT_NONE:
-                return float((a - t).abs().mean(1).max())
-            worst = 0.0
-            if act == ACT_SIGMOID:      # shifts that put the map's mean at 0.5 ... 0.03
-                shifts = [float(v) for v in torch.linspace(-5.0, 1.0, 13)]
-                centre = -t.median(dim=1, keepdim=True).values
-            else:                       # ReLU: shifts that leave 95 % ... 5 % of the map positive
-                qs = torch.tensor([0.05, 0.2, 0.35, 0.5, 0.65, 0.8, 0.9, 0.95], dtype=t.dtype, device=t.device)
-                shifts, centre = None, -torch.quantile(t, qs, dim=1).t()        # [n, len(qs)]
-            for j in range(len(shifts) if shifts is not None else centre.shape[1]):
-                d = centre + shifts[j] if shifts is not None else centre[:, j:j + 1]
+            if act == ACT_NONE:      # a shift of bare logits changes nothing but the denominator: one point per image, e = eps r exactly
+                den = t.abs().sum(1).clamp_min(1e-300)
+                return (t.shape[1] / den).unsqueeze(1), ((a - t).abs().sum(1) / den).unsqueeze(1)
+            if act == ACT_SIGMOID:      # shifts that put the map's mean between ~0.9 and ~0.02
+                grid = -t.median(dim=1, keepdim=True).values + torch.linspace(-5.0, 2.0, 29, dtype=t.dtype, device=t.device)[None, :]
+            else:                       # ReLU: shifts that leave 97 % ... 3 % of the map positive
+                qs = torch.tensor([0.03, 0.08, 0.15, 0.25, 0.35, 0.5, 0.65, 0.75, 0.85, 0.92, 0.97], dtype=t.dtype, device=t.device)
+                grid = -torch.quantile(t, qs, dim=1).t()
+            R, Em = [], []
+            for j in range(grid.shape[1]):
+                d = grid[:, j:j + 1]
                 if act == ACT_SIGMOID:
                     fa, ft = torch.sigmoid(a + d), torch.sigmoid(t + d)
                     wsum = (ft * (1 - ft)).sum(1)
                 else:
                     fa, ft = (a + d).clamp_min(0), (t + d).clamp_min(0)
                     wsum = (ft > 0).double().sum(1)
-                worst = max(worst, float(((fa - ft).abs().sum(1) / wsum.clamp_min(1.0)).max()))
-            return worst
-        e1 = eps(z1)
-        res = dict(budget=budget, safety=safety, images=len(use), size=(H, W), eps1=e1, act={ACT_SIGMOID: "sigmoid", ACT_RELU: "relu", ACT_NONE: "none"}[act])
+                den = ft.sum(1).clamp_min(1e-300)
+                R.append(wsum / den)
+                Em.append((fa - ft).abs().sum(1) / den)
+            return torch.stack(R, 1), torch.stack(Em, 1)
+
+        def thresholds(zk):
+            """(largest eps = e / r over the points, the threshold of the `global` rule budget / (safety eps_max), the threshold of the `cross` rule: the smallest r
+            at which a calibration point exceeds the budget -- the rung's error AT the operating point where it would be left, not its worst anywhere)"""
+            R, Em = curve(zk)
+            eps_max = float((Em / R.clamp_min(1e-300)).max())
+            bad = Em * safety > budget
+            r_cross = float(R[bad].min()) if bool(bad.any()) else float("inf")
+            return eps_max, budget / (safety * max(eps_max, 1e-30)), r_cross
+        cap = (lambda v, lo: min(max(v, lo), 0.97)) if act == ACT_SIGMOID else (lambda v, lo: max(v, lo))      # a sigmoid's r lives in (0, 1)
+        e1, g1, c1 = thresholds(z1)
+        res = dict(budget=budget, safety=safety, rule=rule, images=len(use), size=(H, W), eps1=e1, r_global=g1, r_cross=c1,
+                   act={ACT_SIGMOID: "sigmoid", ACT_RELU: "relu", ACT_NONE: "none"}[act])
+        pick = (lambda g, c: c if rule == "cross" else g)
         if z2 is not None:
-            e2 = eps(z2)
-            r = budget / (safety * max(e1, 1e-30))
-            res.update(eps2=e2, r=min(max(r, 0.02), 0.97), r3=min(max(budget / (safety * max(e2, 1e-30)), min(max(r, 0.02), 0.97)), 0.985))
+            e2, g2, c2 = thresholds(z2)
+            r = cap(pick(g1, c1), 0.02)
+            res.update(eps2=e2, r3_global=g2, r3_cross=c2, r=r, r3=cap(pick(g2, c2), r))
         else:
-            res.update(r3=budget / (safety * max(e1, 1e-30)))
+            res.update(r3=cap(pick(g1, c1), 0.0))
         if flat_index is not None:
             dmin, dflat = float(tap_div[use].min()), float(tap_div[flat_index])
             res.update(tap_diversity_images_min=dmin, tap_diversity_flat=dflat, div=math.sqrt(dmin * dflat) if dflat < 0.25 * dmin else 0.0)
@@ -983,8 +1015,17 @@ class DepthEngine:
                 return dict(K=2 * D, lda=ldy, f8_from=D, f8_mid=D + D // 2, f8_scales=blk_[wname.replace("_w", "_f8")])
             return dict(K=3 * D, lda=ldy, a_dup_seg=D)
 
-        def a_act(blk_, kin):       # ... that reads an operand-typed activation of width kin: plain, or walked twice against [w_hi | w_lo]
-            return dict(K=2 * kin, lda=kin, a_wrap=kin) if blk_["esplit"] else dict(K=kin, lda=kin)
+        ldo, ldh = ws.o.shape[1], ws.hd.shape[1]
+
+        def a_act(blk_, kin, ld, wname):       # ... that reads the attention output / the MLP hidden (width kin, row stride ld): plain, or the split forms its producer wrote
+            if not blk_["esplit"]:
+                return dict(K=kin, lda=ld)
+            if w.enc_f8:
+                return dict(K=2 * kin, lda=ld, f8_from=kin, f8_mid=kin + kin // 2, f8_scales=blk_[wname.replace("_w", "_f8")])
+            return dict(K=3 * kin, lda=ld, a_dup_seg=kin)
+
+        def seg_act(blk_, kin):     # split_seg of the producer of such an activation
+            return (-kin if w.enc_f8 else kin) if blk_["esplit"] else 0
 
         def seg(blk_):              # split_seg of the LayerNorm that feeds blk_'s linear layers
             return (-D if w.enc_f8 else D) if blk_["esplit"] else 0
@@ -997,21 +1038,21 @@ class DepthEngine:
             else:
                 k_layernorm(ws.x, D, T, D, blk["ln1_w"], blk["ln1_b"], LN_EPS, out_op=ws.y, ld_op=ldy, split_seg=seg(blk))
                 k_igemm(M=T, N=3 * D, k_alg=D, A=ws.y, W=blk["qkv_w"], bias=blk["qkv_b"], flags=EP_BIAS, out_op=ws.qkv, ldo_op=3 * D, **a_ln(blk, "qkv_w"))
-            k_attention(ws.qkv, ws.o, B, N, heads)
+            k_attention(ws.qkv, ws.o, B, N, heads, ld_out=ldo if ldo != D else 0, split_seg=seg_act(blk, D))
             hid = blk["hidden"]
             k_igemm(M=T, N=D, k_alg=D, A=ws.o, W=blk["proj_w"], bias=blk["proj_b"], gamma=blk["ls1"], res=ws.x, ldr=D,
-                    flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, D))
+                    flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, D, ldo, "proj_w"))
             k_layernorm(ws.x, D, T, D, blk["ln2_w"], blk["ln2_b"], LN_EPS, out_op=ws.y, ld_op=ldy, split_seg=seg(blk))
             if w.ffn == "mlp":
                 k_igemm(M=T, N=hid, k_alg=D, A=ws.y, W=blk["fc1_w"], bias=blk["fc1_b"], flags=EP_BIAS | EP_GELU,
-                        out_op=ws.hd, ldo_op=hid, **a_ln(blk, "fc1_w"))
+                        out_op=ws.hd, ldo_op=ldh, split_seg=seg_act(blk, hid), **a_ln(blk, "fc1_w"))
                 k_igemm(M=T, N=D, k_alg=hid, A=ws.hd, W=blk["fc2_w"], bias=blk["fc2_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
-                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, hid))
+                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, hid, ldh, "fc2_w"))
             else:
                 k_igemm(M=T, N=2 * hid, k_alg=D, A=ws.y, W=blk["w12_w"], bias=blk["w12_b"], flags=EP_BIAS | EP_SWIGLU,
-                        out_op=ws.hd, ldo_op=hid, **a_ln(blk, "w12_w"))
+                        out_op=ws.hd, ldo_op=ldh, split_seg=seg_act(blk, hid), **a_ln(blk, "w12_w"))
                 k_igemm(M=T, N=D, k_alg=hid, A=ws.hd, W=blk["w3_w"], bias=blk["w3_b"], gamma=blk["ls2"], res=ws.x, ldr=D,
-                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, hid))
+                        flags=EP_BIAS | EP_GAMMA | EP_RESIDUAL, out_f32=ws.x, ldo_f32=D, **a_act(blk, hid, ldh, "w3_w"))
             if self.block_probe is not None:      # diagnostic (tools/stage_errors.py): the residual stream behind block i
                 self.block_probe(i, ws)
             if i in taps:  # shared final LayerNorm on the tap, cls row dropped (dinov2.py:337-340)
@@ -1059,48 +1100,50 @@ class DepthEngine:
                 k_igemm(M=B * Np, N=D, k_alg=D, A=ws.taps[i], W=w.ro_wx[i], bias=ws.cls_bias[i], bias_row_mod=Np, **self._kdup(KDr, w.ro_wx[i], a_seg=ws.tap_seg),
                         flags=EP_BIAS | EP_GELU, out_op=ws.taps_ro[i], ldo_op=ws.taps_ro[i].shape[1], split_seg=S("proj", D))
             taps_in = ws.taps_ro
-        # ---- reassemble: 1x1 project + resize (dpt.py:171-173) -> zero-bordered NHWC operand tensors -----
+        # ---- per level i: reassemble (1x1 project + resize, dpt.py:171-173) -> [amodal: input_projection = conv3x3 -> channels-first LN -> ReLU,
+        #      dpt.py:153-159,178-179] -> layerN_rn (blocks.py:20-24): fp32 copy for the residual adds + ReLU'd operand copy for conv1.  The four chains are
+        #      independent (chain(i) below touches level-i buffers only) -----
         KD = ws.taps[0].shape[1]
-        for i, s_ in ((0, 4), (1, 2)):
-            if i in w.sp:     # 1x1 project -> zero-bordered patch-grid tensor; the transposed conv runs inside the sub-pixel convolution below
-                k_igemm(M=P, N=oc[i], k_alg=D, A=taps_in[i], W=w.proj_w[i], **self._kdup(KD, w.proj_w[i], a_seg=ws.tap_seg), bias=w.proj_b[i], flags=EP_BIAS,
-                        out_op=ws.tp[i], ldo_op=ocp[i], map_op=MAP_PAD, map_h=ph, map_w=pw)
-                continue
-            t = ws.t0 if i == 0 else ws.t1
-            rs_w, rs_b = (w.rs0_w, w.rs0_b) if i == 0 else (w.rs1_w, w.rs1_b)
-            k_igemm(M=P, N=oc[i], k_alg=D, A=taps_in[i], W=w.proj_w[i], **self._kdup(KD, w.proj_w[i], a_seg=ws.tap_seg), bias=w.proj_b[i], flags=EP_BIAS, out_op=t, ldo_op=t.shape[1], split_seg=S(f"rs{i}", ocp[i]))
-            k_igemm(M=P, N=s_ * s_ * oc[i], k_alg=oc[i], A=t, W=rs_w, bias=rs_b, flags=EP_BIAS, **self._kdup(t.shape[1], rs_w),
-                    out_op=ws.L[i], ldo_op=ws.L[i].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=s_, shuffle_c=oc[i], split_seg=S(f"{first}{i}", ocp[i]))
-        k_igemm(M=P, N=oc[2], k_alg=D, A=taps_in[2], W=w.proj_w[2], **self._kdup(KD, w.proj_w[2], a_seg=ws.tap_seg), bias=w.proj_b[2], flags=EP_BIAS,
-                out_op=ws.L[2], ldo_op=ws.L[2].shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S(first + "2", ocp[2]))
-        k_igemm(M=P, N=oc[3], k_alg=D, A=taps_in[3], W=w.proj_w[3], **self._kdup(KD, w.proj_w[3], a_seg=ws.tap_seg), bias=w.proj_b[3], flags=EP_BIAS,
-                out_op=ws.pre3, ldo_op=ws.pre3.shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S("rs3", ocp[3]))
-        self._conv3(ws.pre3, w.rs3_w, rows[3], oc[3], grid[3], stride=2, cin=oc[3], bias=w.rs3_b, flags=EP_BIAS,
-                    out_op=ws.L[3], ldo_op=ws.L[3].shape[3], map_op=MAP_PAD, map_h=grid[3][0], map_w=grid[3][1], split_seg=S(first + "3", ocp[3]))
 
-        # ---- amodal only: input_projection = conv3x3 -> channels-first LN -> ReLU (dpt.py:153-159,178-179) ----
-        layers = ws.L
-        if w.amodal_head:
-            for i in range(4):
-                if i in w.sp:
-                    # resize_layers[i] + input_projection[i][0] as one sub-pixel convolution over the patch grid: [P, s*s*oc] fp32, column block
-                    # (py*s + px) = output phase; the LayerNorm reads it in fine-pixel order and takes the transposed conv's bias back out where
-                    # a tap falls into the zero padding (the outermost ring of the fine grid)
-                    sp = w.sp[i]
-                    ncol = sp["s"] * sp["s"] * oc[i]
-                    self._conv3(ws.tp[i], sp["w"], P, ncol, (ph, pw), k_alg=sp["taps_per_col"] * oc[i], bias=sp["b"], flags=EP_BIAS,
-                                out_f32=ws.ipf[i], ldo_f32=ncol, tap_cols=oc[i], tap_mask=sp["masks"])
-                    k_layernorm(ws.ipf[i], ncol, rows[i], oc[i], w.ip_ln_w[i], w.ip_ln_b[i], LN_EPS, out_op=ws.L2[i], ld_op=ws.L2[i].shape[3],
-                                map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], relu=True, split_seg=S(f"rn{i}", ocp[i]),
-                                unshuffle_s=sp["s"], tap_bias=sp["tapb"])
-                    continue
-                self._conv3(ws.L[i], w.ip_w[i], rows[i], oc[i], grid[i], cin=oc[i], bias=w.ip_b[i], flags=EP_BIAS, out_f32=ws.ipf[i], ldo_f32=oc[i])
-                k_layernorm(ws.ipf[i], oc[i], rows[i], oc[i], w.ip_ln_w[i], w.ip_ln_b[i], LN_EPS, out_op=ws.L2[i],
-                            ld_op=ws.L2[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], relu=True, split_seg=S(f"rn{i}", ocp[i]))
-            layers = ws.L2
+        def reassemble(i):
+            if i < 2:
+                s_ = 4 if i == 0 else 2
+                if i in w.sp:     # 1x1 project -> zero-bordered patch-grid tensor; the transposed conv runs inside the sub-pixel convolution below
+                    k_igemm(M=P, N=oc[i], k_alg=D, A=taps_in[i], W=w.proj_w[i], **self._kdup(KD, w.proj_w[i], a_seg=ws.tap_seg), bias=w.proj_b[i], flags=EP_BIAS,
+                            out_op=ws.tp[i], ldo_op=ocp[i], map_op=MAP_PAD, map_h=ph, map_w=pw)
+                    return
+                t = ws.t0 if i == 0 else ws.t1
+                rs_w, rs_b = (w.rs0_w, w.rs0_b) if i == 0 else (w.rs1_w, w.rs1_b)
+                k_igemm(M=P, N=oc[i], k_alg=D, A=taps_in[i], W=w.proj_w[i], **self._kdup(KD, w.proj_w[i], a_seg=ws.tap_seg), bias=w.proj_b[i], flags=EP_BIAS, out_op=t, ldo_op=t.shape[1], split_seg=S(f"rs{i}", ocp[i]))
+                k_igemm(M=P, N=s_ * s_ * oc[i], k_alg=oc[i], A=t, W=rs_w, bias=rs_b, flags=EP_BIAS, **self._kdup(t.shape[1], rs_w),
+                        out_op=ws.L[i], ldo_op=ws.L[i].shape[3], map_op=MAP_SHUFFLE, map_h=ph, map_w=pw, shuffle_s=s_, shuffle_c=oc[i], split_seg=S(f"{first}{i}", ocp[i]))
+            elif i == 2:
+                k_igemm(M=P, N=oc[2], k_alg=D, A=taps_in[2], W=w.proj_w[2], **self._kdup(KD, w.proj_w[2], a_seg=ws.tap_seg), bias=w.proj_b[2], flags=EP_BIAS,
+                        out_op=ws.L[2], ldo_op=ws.L[2].shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S(first + "2", ocp[2]))
+            else:
+                k_igemm(M=P, N=oc[3], k_alg=D, A=taps_in[3], W=w.proj_w[3], **self._kdup(KD, w.proj_w[3], a_seg=ws.tap_seg), bias=w.proj_b[3], flags=EP_BIAS,
+                        out_op=ws.pre3, ldo_op=ws.pre3.shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=S("rs3", ocp[3]))
+                self._conv3(ws.pre3, w.rs3_w, rows[3], oc[3], grid[3], stride=2, cin=oc[3], bias=w.rs3_b, flags=EP_BIAS,
+                            out_op=ws.L[3], ldo_op=ws.L[3].shape[3], map_op=MAP_PAD, map_h=grid[3][0], map_w=grid[3][1], split_seg=S(first + "3", ocp[3]))
 
-        # ---- layerN_rn (blocks.py:20-24): fp32 copy for the residual adds + ReLU'd operand copy for conv1 ----
-        for i in range(4):
+        def input_projection(i):      # amodal only
+            if i in w.sp:
+                # resize_layers[i] + input_projection[i][0] as one sub-pixel convolution over the patch grid: [P, s*s*oc] fp32, column block
+                # (py*s + px) = output phase; the LayerNorm reads it in fine-pixel order and takes the transposed conv's bias back out where
+                # a tap falls into the zero padding (the outermost ring of the fine grid)
+                sp = w.sp[i]
+                ncol = sp["s"] * sp["s"] * oc[i]
+                self._conv3(ws.tp[i], sp["w"], P, ncol, (ph, pw), k_alg=sp["taps_per_col"] * oc[i], bias=sp["b"], flags=EP_BIAS,
+                            out_f32=ws.ipf[i], ldo_f32=ncol, tap_cols=oc[i], tap_mask=sp["masks"])
+                k_layernorm(ws.ipf[i], ncol, rows[i], oc[i], w.ip_ln_w[i], w.ip_ln_b[i], LN_EPS, out_op=ws.L2[i], ld_op=ws.L2[i].shape[3],
+                            map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], relu=True, split_seg=S(f"rn{i}", ocp[i]),
+                            unshuffle_s=sp["s"], tap_bias=sp["tapb"])
+                return
+            self._conv3(ws.L[i], w.ip_w[i], rows[i], oc[i], grid[i], cin=oc[i], bias=w.ip_b[i], flags=EP_BIAS, out_f32=ws.ipf[i], ldo_f32=oc[i])
+            k_layernorm(ws.ipf[i], oc[i], rows[i], oc[i], w.ip_ln_w[i], w.ip_ln_b[i], LN_EPS, out_op=ws.L2[i],
+                        ld_op=ws.L2[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], relu=True, split_seg=S(f"rn{i}", ocp[i]))
+
+        def layer_rn(i):
             if not w.amodal_head and i in w.sp:
                 # raw head: resize_layers[i] + layer{i+1}_rn as one sub-pixel convolution over the patch grid, then ONE re-layout pass: fine-pixel
                 # order, the transposed conv's bias taken out on the outermost ring, fp32 copy for the residual adds + ReLU'd operand copy
@@ -1111,8 +1154,9 @@ class DepthEngine:
                 k_layernorm(ws.spf[i], ncol, rows[i], Fch, None, None, LN_EPS, identity=True, relu=2, out_f32=ws.rnx[i], ld_f32=Fch, out_op=ws.rnr[i],
                             ld_op=ws.rnr[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], split_seg=S(f"rcu{i}", Fp),
                             unshuffle_s=sp["s"], tap_bias=sp["tapb"])
-                continue
-            self._conv3(layers[i], w.rn_w[i], rows[i], Fch, grid[i], cin=oc[i], flags=EP_RELU_OP, out_f32=ws.rnx[i], ldo_f32=Fch,
+                return
+            src = ws.L2[i] if w.amodal_head else ws.L[i]
+            self._conv3(src, w.rn_w[i], rows[i], Fch, grid[i], cin=oc[i], flags=EP_RELU_OP, out_f32=ws.rnx[i], ldo_f32=Fch,
                         out_op=ws.rnr[i], ldo_op=ws.rnr[i].shape[3], map_op=MAP_PAD, map_h=grid[i][0], map_w=grid[i][1], split_seg=S(f"rcu{i}", Fp))
 
         def rcu(i, fw, unit, src_relu_pad, src_f32, **out):
@@ -1122,6 +1166,31 @@ class DepthEngine:
                         out_op=ws.tmpa[i], ldo_op=ws.tmpa[i].shape[3], map_op=MAP_PAD, map_h=g[0], map_w=g[1], split_seg=S(f"rcu{i}", Fp))
             self._conv3(ws.tmpa[i], fw[f"u{unit}c2_w"], rows[i], Fch, g, cin=Fch, bias=fw[f"u{unit}c2_b"], res=src_f32, ldr=Fch,
                         flags=EP_BIAS | EP_RESIDUAL, **out)
+
+        def chain(i):     # everything of level i that does not depend on another level; RCU 1 of levels 0-2 (blocks.py:131-133) reads rnr / rnx of its own level only
+            reassemble(i)
+            if w.amodal_head:
+                input_projection(i)
+            layer_rn(i)
+            if i < 3:
+                rcu(i, w.fuse[i], 1, ws.rnr[i], ws.rnx[i], out_f32=ws.r[i], ldo_f32=Fch)
+
+        # (r[i] lives in ipf[i] where that is large enough and zf[i] in rnx[i] -- Workspace: both are dead by the time they are overwritten INSIDE chain i / after the join)
+        forked = HEAD_STREAMS == "1" or (HEAD_STREAMS == "auto" and P <= HEAD_STREAMS_ROWS)
+        if forked and not instrumented():
+            cur = torch.cuda.current_stream(ws.oc1.device)
+            side = self._side_streams(ws.oc1.device)
+            for st_ in side:
+                st_.wait_stream(cur)
+            chain(0)                      # the finest level -- most of the work -- stays on the caller's stream
+            for i, st_ in zip((1, 2, 3), side):
+                with torch.cuda.stream(st_):
+                    chain(i)
+            for st_ in side:
+                cur.wait_stream(st_)
+        else:
+            for i in range(4):
+                chain(i)
 
         # ---- refinenet4..1 (blocks.py:123-148).  out_conv is applied BEFORE the bilinear resize: both are linear and
         #      the align_corners weights sum to one, so conv1x1(resize(x)) == resize(conv1x1(x)) at a quarter of the MACs.
@@ -1135,7 +1204,6 @@ class DepthEngine:
                     out_f32=ws.zf[i], ldo_f32=Fch)
             if i > 0:
                 j = i - 1
-                rcu(j, w.fuse[j], 1, ws.rnr[j], ws.rnx[j], out_f32=ws.r[j], ldo_f32=Fch)
                 k_bilinear(ws.zf[i], Fch, B, grid[i][0], grid[i][1], grid[j][0], grid[j][1], Fch, add=ws.r[j], ld_add=Fch,
                            out_f32=ws.s[j], ld_f32=Fch, out_op=ws.sr[j], ld_op=ws.sr[j].shape[3], map_op=MAP_PAD, relu=True, split_seg=S(f"rcu{j}", Fp))
                 s_f32, s_pad = ws.s[j], ws.sr[j]

@@ -219,8 +219,9 @@ _LADDER_F8 = "head"
 # checkpoint has no reason to share.  The error budget is what is stated instead: a rung is left where its sensitivity-normalised logit error times the
 # image's r reaches _LADDER_BUDGET of the 1e-3 bar.  What is left below are the UNCALIBRATED fallbacks, used only where the calibration cannot run (the
 # first forward arrives inside a caller's stream capture) or is switched off (ADA_LADDER_CALIBRATE=0): one conservative set for every encoder.
-_LADDER_BUDGET = float(_os.environ.get("ADA_LADDER_BUDGET", "8e-4"))
-_LADDER_SAFETY = 1.1          # on the largest eps the calibration images show
+_LADDER_BUDGET = float(_os.environ.get("ADA_LADDER_BUDGET", "9e-4"))
+_LADDER_SAFETY = float(_os.environ.get("ADA_LADDER_SAFETY", "1.1"))          # on the error the calibration images show
+_LADDER_RULE = _os.environ.get("ADA_LADDER_RULE", "cross")                   # cross | global (hip_ext.engine.DepthEngine.calibrate)
 _LADDER_FALLBACK = dict(r=0.40, r3=0.75, div=0.10)
 _LADDER_CALIBRATE = _os.environ.get("ADA_LADDER_CALIBRATE", "1") != "0"
 _LADDER_CAL_SIZE = tuple(int(v) for v in _os.environ.get("ADA_LADDER_CAL_SIZE", "266x322").split("x"))
@@ -372,7 +373,7 @@ class _EngineMixin:
 
     def _calibrate_ladder(self, eng, plist, explicit_r=False):
         """Installs the calibrated thresholds (hip_ext.engine.DepthEngine.calibrate) into the engine's ladder and exposes the numbers as
-        ``module.ladder_calibration``.  Calibration set: two noise and two image-like synthetic inputs (src/util/synth_weights.make_inputs; the guide tensor takes
+        ``module.ladder_calibration``.  Calibration set: four noise and four image-like synthetic inputs (src/util/synth_weights.make_inputs; the guide tensor takes
         the trailing channels of [rgb | mask | observation], whatever the guide_type) plus one all-zero image that places the tap-diversity threshold, at
         _LADDER_CAL_SIZE.  Cached by the stamp of every parameter BUT the final 1x1 bias (the logit error does not depend on it -- the bias is added in fp32 -- and
         callers that sweep the operating point rewrite exactly that tensor).  A threshold the caller named (module.precision_ladder = <float> / ADA_LADDER_R)
@@ -383,20 +384,20 @@ class _EngineMixin:
             object.__setattr__(self, "ladder_calibration", None)
             return
         skip = "depth_head.scratch.output_conv2.2.bias"
-        key = tuple((v.data_ptr(), v._version) for n, v in zip(self._engine_pnames, plist) if n != skip) + (getattr(self, "f8_terms", None), _LADDER_BUDGET, _LADDER_CAL_SIZE)
+        key = tuple((v.data_ptr(), v._version) for n, v in zip(self._engine_pnames, plist) if n != skip) + (getattr(self, "f8_terms", None), _LADDER_BUDGET, _LADDER_SAFETY, _LADDER_RULE, _LADDER_CAL_SIZE)
         cal = self.__dict__.get("_ladder_cal")
         if cal is None or cal[0] != key:
             from src.util.synth_weights import make_inputs
             dev = plist[0].device
             H, W = _LADDER_CAL_SIZE
-            parts = [make_inputs(2, H, W, seed=9001, device=dev, style="noise"), make_inputs(2, H, W, seed=9002, device=dev, style="structured"),
+            parts = [make_inputs(4, H, W, seed=9001, device=dev, style="noise"), make_inputs(4, H, W, seed=9002, device=dev, style="structured"),
                      make_inputs(1, H, W, seed=0, device=dev, style="zeros")]
             x = _torch.cat([p[0] for p in parts], 0)
             guide = None
             cg = eng.w.guide_channels if eng.w.guided else 0
             if cg:
                 guide = _torch.cat([_torch.cat([p[1], p[2], p[3]], 1) for p in parts], 0)[:, 5 - cg:].contiguous()
-            cal = (key, eng.calibrate(x, guide, budget=_LADDER_BUDGET, safety=_LADDER_SAFETY, flat_index=x.shape[0] - 1))
+            cal = (key, eng.calibrate(x, guide, budget=_LADDER_BUDGET, safety=_LADDER_SAFETY, flat_index=x.shape[0] - 1, rule=_LADDER_RULE))
             object.__setattr__(self, "_ladder_cal", cal)
         res = dict(cal[1])
         if "r" in lad and not explicit_r and "r" in res:

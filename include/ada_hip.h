@@ -175,6 +175,12 @@ int ada_igemm(const ada_igemm_args* args, void* stream);
  * ---------------------------------------------------------------------------------------- */
 int ada_attention_fwd(const void* qkv, void* out, int32_t batch, int32_t n_tokens, int32_t heads,
                       void* stream);
+/* ABI 8: the same with a row stride for `out` (ld_out elements; 0 = heads * 64) and a split-precision output for the blocks whose linear layers run in split
+ * precision -- the attention output feeds attn.proj (attention.py:60) and exists in the operand type only.  split_seg > 0: row = [hi | lo], lo = round(v - hi) at
+ * column + split_seg;  split_seg < 0, seg = -split_seg: row = [hi: seg elements | lo8: seg bytes | hi8: seg bytes] (e5m2((v - hi) 2^10), e5m2(v)) -- the forms
+ * ada_igemm reads through a_dup_seg / f8_from.  |split_seg| >= heads * 64, ld_out >= 2 |split_seg|.  0 = the plain row. */
+int ada_attention_ex(const void* qkv, void* out, int32_t batch, int32_t n_tokens, int32_t heads, int64_t ld_out, int32_t split_seg,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension, eps inside the sqrt, biased variance, fp32 statistics:

@@ -228,3 +228,91 @@ def test_f8_arguments_are_validated(hip):
             hip.igemm(M=256, N=64, K=512, A=A, lda=512, W=W, out_f32=out, ldo_f32=64, f8_scales=0x7f7f7f7f, **bad)
     with pytest.raises(hip.HipExtError):
         hip.igemm(M=256, N=64, K=512, A=A, lda=256, a_wrap=256, W=W, out_f32=out, ldo_f32=64, f8_from=256, f8_mid=384, f8_scales=0x7f7f7f7f)
+
+
+# ---- round 6: the activations that exist in the operand type only -- attention output (feeds attn.proj), SwiGLU hidden (feeds mlp.w3) -- in the split forms ----
+@pytest.mark.parametrize("B,N,heads,ld", [(2, 1370, 2, 256), (1, 65, 3, 384), (3, 200, 6, 1024)])
+def test_attention_split_output_forms(hip, B, N, heads, ld):
+    """ada_attention_ex: the plain row with a stride, [hi | lo] (split_seg > 0) and [hi | lo8 | hi8] (split_seg < 0).  The hi segment is the plain output bit for
+    bit; hi + lo is the kernel's fp32 value (so it is nearer the fp32 softmax(QK^T)V than hi alone, and |lo| <= ulp(hi) / 2); the byte segments are the e5m2
+    roundings of that value's residual x 2^10 and of the value."""
+    _need_f16(hip)
+    op = torch.float16
+    LOG2E = 1.4426950408889634
+    D = heads * 64
+    seg = ld // 2
+    qkv = _rand(B * N, 3 * D, seed=633)
+    qkv[:, :D] *= 0.125 * LOG2E
+    qkv = qkv.to(op).to(DEV)
+    plain = torch.zeros(B * N, D, dtype=op, device=DEV)
+    hip.attention(qkv, plain, B, N, heads)
+    strided = torch.zeros(B * N, ld, dtype=op, device=DEV)
+    hip.attention(qkv, strided, B, N, heads, ld_out=ld)
+    assert torch.equal(strided[:, :D], plain) and float(strided[:, D:].abs().max()) == 0.0
+    two = torch.zeros(B * N, ld, dtype=op, device=DEV)
+    hip.attention(qkv, two, B, N, heads, ld_out=ld, split_seg=seg)
+    assert torch.equal(two[:, :D], plain)
+    hi, lo = two[:, :D].float().cpu(), two[:, seg:seg + D].float().cpu()
+    assert float(lo.abs().max()) > 0 and bool((lo.abs() <= hi.abs() * 2.0 ** -11 + 6.0e-8).all())
+    t = qkv.float().cpu().reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = (((t[0] @ t[1].transpose(-2, -1)) / LOG2E).softmax(-1) @ t[2]).transpose(1, 2).reshape(B * N, D)
+    e_hi, e_two = float((hi - ref).abs().mean()), float((hi + lo - ref).abs().mean())
+    print(f"attention B={B} N={N} heads={heads}: mean |err| of hi {e_hi:.3e}, of hi + lo {e_two:.3e}")
+    assert e_two <= e_hi
+    f8 = torch.zeros(B * N, ld, dtype=op, device=DEV)
+    hip.attention(qkv, f8, B, N, heads, ld_out=ld, split_seg=-seg)
+    b = f8.cpu().contiguous().view(torch.uint8).reshape(B * N, 2 * ld)
+    assert torch.equal(b[:, :2 * D].contiguous().view(op), plain.cpu())
+    lo8, hi8 = b[:, 2 * seg:2 * seg + D], b[:, 3 * seg:3 * seg + D]
+    want_lo8, want_hi8 = _e5m2(lo * 1024.0).view(torch.uint8), _e5m2(hi + lo).view(torch.uint8)
+    frac = float(((lo8 == want_lo8) & (hi8 == want_hi8)).float().mean())
+    assert frac > 0.99, f"only {frac:.4f} of the (lo8, hi8) pairs are the e5m2 roundings of the kernel's value"
+    for a, z in ((2 * D, 2 * seg), (2 * seg + D, 3 * seg), (3 * seg + D, 4 * seg)):
+        if z > a:
+            assert int(b[:, a:z].max()) == 0, "pad bytes written"
+
+
+@pytest.mark.parametrize("cfg", [-1, 3, 4])
+def test_swiglu_split_output_forms_and_the_w3_contraction(hip, forced_tile, cfg):
+    """EP_SWIGLU with split_seg: the gated hidden silu(x1) * x2 (swiglu_ffn.py:31-32) written [hi | lo] and [hi | lo8 | hi8], then contracted by a w3-shaped
+    launch (f8_from) -- against the exact product of the fp32 hidden with the fp32 weights: ~1e-5 where the plain fp16 hidden leaves ~3e-4."""
+    _need_f16(hip)
+    from hip_ext.engine import f8_weight_split
+    op = torch.float16
+    if cfg >= 0:
+        forced_tile(cfg, 4)
+    M, K, Hd, N = 1000, 128, 256, 192
+    A = _rand(M, K, seed=640).to(op).to(DEV)
+    w12 = (_rand(2 * Hd, K, seed=641) * K ** -0.5).to(op)
+    b12 = _rand(2 * Hd, seed=642)
+    idx = torch.arange(Hd).reshape(-1, 32)
+    order = torch.stack([idx, idx + Hd], dim=1).reshape(-1)
+    x12 = A.double().cpu() @ w12.double().T + b12.double()
+    ref = (F.silu(x12[:, :Hd]) * x12[:, Hd:]).float()
+    kw = dict(M=M, N=2 * Hd, K=K, A=A, lda=K, W=w12[order].contiguous().to(DEV), bias=b12[order].contiguous().to(DEV), flags=hip.EP_BIAS | hip.EP_SWIGLU)
+    plain = torch.zeros(M, Hd, dtype=op, device=DEV)
+    hip.igemm(out_op=plain, ldo_op=Hd, **kw)
+    two = torch.zeros(M, 2 * Hd, dtype=op, device=DEV)
+    hip.igemm(out_op=two, ldo_op=2 * Hd, split_seg=Hd, **kw)
+    assert torch.equal(two[:, :Hd], plain)
+    rec = two[:, :Hd].float().cpu() + two[:, Hd:].float().cpu()
+    assert float((rec - ref).abs().max() / ref.abs().max()) < 2e-5
+    f8 = torch.zeros(M, 2 * Hd, dtype=op, device=DEV)
+    hip.igemm(out_op=f8, ldo_op=2 * Hd, split_seg=-Hd, **kw)
+    b = f8.cpu().contiguous().view(torch.uint8).reshape(M, 4 * Hd)
+    assert torch.equal(b[:, :2 * Hd].contiguous().view(op), plain.cpu())
+    lo = two[:, Hd:].float().cpu()
+    frac = float(((b[:, 2 * Hd:3 * Hd] == _e5m2(lo * 1024.0).view(torch.uint8)) & (b[:, 3 * Hd:] == _e5m2(rec).view(torch.uint8))).float().mean())
+    assert frac > 0.99, f"only {frac:.4f} of the (lo8, hi8) pairs are the e5m2 roundings of the epilogue's value"
+    # the consumer: mlp.w3 over the split hidden, fp8 correction terms
+    w3 = _rand(N, Hd, seed=643) * Hd ** -0.5
+    packed, word = f8_weight_split(w3.to(DEV), op)
+    out = torch.zeros(M, N, device=DEV)
+    hip.igemm(M=M, N=N, K=2 * Hd, A=f8, lda=2 * Hd, W=packed, f8_from=Hd, f8_mid=Hd + Hd // 2, f8_scales=word, out_f32=out, ldo_f32=N)
+    single = torch.zeros(M, N, device=DEV)
+    hip.igemm(M=M, N=N, K=Hd, A=plain, lda=Hd, W=w3.to(op).to(DEV), out_f32=single, ldo_f32=N)
+    exact = (ref.double() @ w3.double().T).float()
+    e8 = float((out.cpu() - exact).abs().mean() / exact.abs().mean())
+    e1 = float((single.cpu() - exact).abs().mean() / exact.abs().mean())
+    print(f"w3 over the split hidden (tile {cfg}): fp8 correction terms {e8:.2e} against the exact product, single precision {e1:.2e}")
+    assert e8 < 4e-5 and e8 < e1 / 4

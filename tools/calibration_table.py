@@ -25,7 +25,8 @@ def main():
     if quick:
         rows = rows[:2] + rows[8:9] + rows[11:13]
     sizes = [(266, 322)] if quick else [(126, 154), (266, 322), (518, 518)]
-    print("# kind encoder loss weights fill | calibration size | eps1 eps2 -> r r3 div (tap diversity: images min / flat) | seconds")
+    print(f"# budget {P._LADDER_BUDGET} safety {P._LADDER_SAFETY} rule {P._LADDER_RULE}")
+    print("# kind encoder loss weights fill | calibration size | eps1 eps2 | r: global cross | r3: global cross -> installed r r3 div (tap diversity: images min / flat) | seconds")
     for kind, enc, loss, wseed, tail in rows:
         case = dict(kind=kind, encoder=enc, guide_type="mask+observation", loss=loss, features=RAW[enc][0], out_channels=RAW[enc][1])
         model = build_product_model(case)
@@ -45,7 +46,7 @@ def main():
             torch.cuda.synchronize()
             c = owner.ladder_calibration or {}
             f = lambda k: ("%.3e" % c[k]) if k in c and c[k] is not None else "-"      # noqa: E731
-            print(f"{kind:6s} {enc} {loss or 'relu':22s} w{wseed} {tail:6s} | {size[0]}x{size[1]} | eps1 {f('eps1')} eps2 {f('eps2')} -> r {f('r_installed')} r3 {f('r3_installed')} "
+            print(f"{kind:6s} {enc} {loss or 'relu':22s} w{wseed} {tail:6s} | {size[0]}x{size[1]} | eps1 {f('eps1')} eps2 {f('eps2')} | r {f('r_global')} {f('r_cross')} | r3 {f('r3_global')} {f('r3_cross')} -> r {f('r_installed')} r3 {f('r3_installed')} "
                   f"div {f('div_installed')} ({f('tap_diversity_images_min')} / {f('tap_diversity_flat')}) | {time.perf_counter() - t0:.2f} s", flush=True)
         del model
         torch.cuda.empty_cache()

@@ -230,6 +230,22 @@ def test_f8_arguments_are_validated(hip):
         hip.igemm(M=256, N=64, K=512, A=A, lda=256, a_wrap=256, W=W, out_f32=out, ldo_f32=64, f8_from=256, f8_mid=384, f8_scales=0x7f7f7f7f)
 
 
+def _check_bytes_against_hi_lo(lo8, hi8, hi, lo, what):
+    """The byte segments of a [hi | lo8 | hi8] row against the [hi | lo] form of the same launch: lo8 = e5m2((v - hi) 2^10), hi8 = e5m2(v) with v the producer's fp32
+    value, of which hi + lo is all the test can see.  e5m2 keeps 2 mantissa bits (relative error <= 2^-3); the fp16 lo is itself rounded -- to a 6e-8 grid where it is
+    subnormal, which it is for the small values these producers write -- so the bytes are compared to that tolerance, not bit for bit (the producer rounds the fp32
+    residual directly, which is the better value)."""
+    v = hi + lo
+    lo_dec = lo8.contiguous().view(torch.float8_e5m2).float() / 1024.0
+    hi_dec = hi8.contiguous().view(torch.float8_e5m2).float()
+    ok_lo = (lo_dec - lo).abs() <= 0.13 * lo.abs() + 1.2e-7
+    ok_hi = (hi_dec - v).abs() <= 0.13 * v.abs() + 1.6e-5      # (e5m2's smallest subnormal is 2^-16)
+    frac = float((ok_lo & ok_hi).float().mean())
+    assert frac > 0.9995, f"{what}: only {frac:.5f} of the (lo8, hi8) pairs decode to the value's residual / the value within e5m2's rounding"
+    back = hi + lo_dec
+    assert float((back - v).abs().max() / v.abs().max()) < 2e-4, what
+
+
 # ---- round 6: the activations that exist in the operand type only -- attention output (feeds attn.proj), SwiGLU hidden (feeds mlp.w3) -- in the split forms ----
 @pytest.mark.parametrize("B,N,heads,ld", [(2, 1370, 2, 256), (1, 65, 3, 384), (3, 200, 6, 1024)])
 def test_attention_split_output_forms(hip, B, N, heads, ld):
@@ -263,10 +279,7 @@ def test_attention_split_output_forms(hip, B, N, heads, ld):
     hip.attention(qkv, f8, B, N, heads, ld_out=ld, split_seg=-seg)
     b = f8.cpu().contiguous().view(torch.uint8).reshape(B * N, 2 * ld)
     assert torch.equal(b[:, :2 * D].contiguous().view(op), plain.cpu())
-    lo8, hi8 = b[:, 2 * seg:2 * seg + D], b[:, 3 * seg:3 * seg + D]
-    want_lo8, want_hi8 = _e5m2(lo * 1024.0).view(torch.uint8), _e5m2(hi + lo).view(torch.uint8)
-    frac = float(((lo8 == want_lo8) & (hi8 == want_hi8)).float().mean())
-    assert frac > 0.99, f"only {frac:.4f} of the (lo8, hi8) pairs are the e5m2 roundings of the kernel's value"
+    _check_bytes_against_hi_lo(b[:, 2 * seg:2 * seg + D], b[:, 3 * seg:3 * seg + D], hi, lo, "attention")
     for a, z in ((2 * D, 2 * seg), (2 * seg + D, 3 * seg), (3 * seg + D, 4 * seg)):
         if z > a:
             assert int(b[:, a:z].max()) == 0, "pad bytes written"
@@ -301,9 +314,7 @@ def test_swiglu_split_output_forms_and_the_w3_contraction(hip, forced_tile, cfg)
     hip.igemm(out_op=f8, ldo_op=2 * Hd, split_seg=-Hd, **kw)
     b = f8.cpu().contiguous().view(torch.uint8).reshape(M, 4 * Hd)
     assert torch.equal(b[:, :2 * Hd].contiguous().view(op), plain.cpu())
-    lo = two[:, Hd:].float().cpu()
-    frac = float(((b[:, 2 * Hd:3 * Hd] == _e5m2(lo * 1024.0).view(torch.uint8)) & (b[:, 3 * Hd:] == _e5m2(rec).view(torch.uint8))).float().mean())
-    assert frac > 0.99, f"only {frac:.4f} of the (lo8, hi8) pairs are the e5m2 roundings of the epilogue's value"
+    _check_bytes_against_hi_lo(b[:, 2 * Hd:3 * Hd], b[:, 3 * Hd:], two[:, :Hd].float().cpu(), two[:, Hd:].float().cpu(), f"swiglu tile {cfg}")
     # the consumer: mlp.w3 over the split hidden, fp8 correction terms
     w3 = _rand(N, Hd, seed=643) * Hd ** -0.5
     packed, word = f8_weight_split(w3.to(DEV), op)

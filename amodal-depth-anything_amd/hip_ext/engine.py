@@ -568,6 +568,7 @@ GRAPH_MODE = os.environ.get("ADA_GRAPH", "auto")
 # "auto": graph replay for calls of up to one 518x518 image.  Measured (profiles/r02_k_hip_graph_latency_ab.txt): the forward is device-bound
 # from ViT-B upwards (replay == launches within 0.5 % at B = 1..8) and host-bound only for a single ViT-S image (3.55 -> 2.62 ms).
 GRAPH_AUTO_PIXELS = int(os.environ.get("ADA_GRAPH_AUTO_PIXELS", str(518 * 518)))
+GRAPH_AUTO_ENCODERS = tuple(e for e in os.environ.get("ADA_GRAPH_AUTO_ENCODERS", "vits").split(",") if e)
 # Bounds of the per-shape caches (LRU): a variable-resolution stream of single images must not grow device memory without limit.  A shape is
 # captured only on its SECOND sighting (a one-off resolution pays no extra warm-up forward, synchronise and empty_cache).
 MAX_GRAPHS = int(os.environ.get("ADA_GRAPH_CACHE", "4"))
@@ -733,7 +734,9 @@ class DepthEngine:
             raise HipExtError("DepthEngine.forward: input must live on a HIP device (no CPU fallback in the product path)")
         norm = self.normalise_input if normalise is None else bool(normalise)
         mode = GRAPH_MODE
-        use = mode == "1" or (mode == "auto" and x.shape[0] * x.shape[-2] * x.shape[-1] <= GRAPH_AUTO_PIXELS)
+        # (round 6: with the head's branches on side streams the plain launches of a single ViT-B / ViT-L image are FASTER than the replay -- 2.68 / 5.27 ms against
+        #  3.00 / 5.84 ms, profiles/r06_g_* -- so "auto" replays only the model that is bound by the host's launch rate: ViT-S)
+        use = mode == "1" or (mode == "auto" and self.w.encoder in GRAPH_AUTO_ENCODERS and x.shape[0] * x.shape[-2] * x.shape[-1] <= GRAPH_AUTO_PIXELS)
         # replay bypasses the Python wrappers: with a KernelTimer or a tile log attached the launches must be issued one by one
         if not use or instrumented() or torch.cuda.is_current_stream_capturing():
             return self._escalate(None, self._forward(x, guide, norm), x, guide, norm)

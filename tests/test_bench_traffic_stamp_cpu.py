@@ -14,7 +14,7 @@ def test_committed_traffic_matches_the_committed_kernel_sources():
     t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     assert t.get("csrc_digest"), "profiles/pmc_traffic.json carries no csrc digest"
     assert t["csrc_digest"] == csrc_digest(), ("profiles/pmc_traffic.json was collected on other kernel sources than the ones in csrc/: re-run "
-                                               "tools/sessions/gpu_r4_final.sh (bench.py would report traffic = null)")
+                                               "tools/sessions/closing.sh (bench.py would report traffic = null)")
     assert t["igemm_bytes_per_launch"] > 1e8 and t["attention_bytes_per_launch"] > 1e8
 
 

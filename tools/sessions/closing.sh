@@ -17,16 +17,16 @@ timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q -s -k "golden or 
 ( time python bench.py > $O/bench_default_flags.json 2> $O/bench_default_flags.err ) 2>&1 | tail -n 3; tail -c 400 $O/bench_default_flags.json
 timeout 900 python tools/run_configs.py 2>&1 | grep -v amdgpu > $O/other_configs.txt; cat $O/other_configs.txt
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/trace -o run -- python3 $R/bench.py --no-cpu-baseline --no-traffic --no-low-mean --steps 5 --warmup 2 > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/trace -o run -- python3 $R/bench.py --no-cpu-baseline --no-traffic --no-low-mean --fixed-ladder 0.6 --steps 5 --warmup 2 > $O/bench_under_rocprof.log 2>&1
 DB=$(find $O/trace -name "*_results.db" | head -n 1)
 [ -n "$DB" ] && python3 $R/tools/rocprof_summary.py $DB > $O/kernel_stats.csv
 head -n 12 $O/kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o run -- python3 $R/bench.py --no-cpu-baseline --no-kernel-timer --no-traffic --no-low-mean --steps 1 --warmup 1 --repeats 0 > $O/pmc_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o run -- python3 $R/bench.py --no-cpu-baseline --no-kernel-timer --no-traffic --no-low-mean --steps 1 --warmup 1 --repeats 0 > $O/pmc_w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o run -- python3 $R/bench.py --no-cpu-baseline --no-kernel-timer --no-traffic --no-low-mean --fixed-ladder 0.6 --steps 1 --warmup 1 --repeats 0 > $O/pmc_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o run -- python3 $R/bench.py --no-cpu-baseline --no-kernel-timer --no-traffic --no-low-mean --fixed-ladder 0.6 --steps 1 --warmup 1 --repeats 0 > $O/pmc_w.log 2>&1
 F=$(find $O/pmc_f -name "*counter_collection.csv" | head -n 1); W=$(find $O/pmc_w -name "*counter_collection.csv" | head -n 1)
 cd $R && python3 tools/pmc_traffic.py $F $W && cp profiles/pmc_traffic.json $O/pmc_traffic.json
 cd /tmp
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -o run -- python3 $R/bench.py --no-cpu-baseline --no-kernel-timer --no-traffic --no-low-mean --steps 1 --warmup 1 --repeats 0 > $O/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -o run -- python3 $R/bench.py --no-cpu-baseline --no-kernel-timer --no-traffic --no-low-mean --fixed-ladder 0.6 --steps 1 --warmup 1 --repeats 0 > $O/pmc_sq.log 2>&1
 S=$(find $O/pmc_sq -name "*counter_collection.csv" | head -n 1); [ -n "$S" ] && python3 $R/tools/pmc_sq_summary.py $S > $O/pmc_sq_summary.json
 head -c 800 $O/pmc_sq_summary.json
 cat > /tmp/cfg2.py <<'PY'
@@ -50,7 +50,7 @@ with torch.no_grad():
         m(x, guide_mask=mask, observation=obs)
 torch.cuda.synchronize()
 PY
-ADA_ROOT=$R rocprofv3 --kernel-trace --stats -d $O/trace_cfg2 -o run -- python3 /tmp/cfg2.py > $O/cfg2_under_rocprof.log 2>&1
+ADA_ROOT=$R ADA_LADDER_CALIBRATE=0 ADA_LADDER_R=0.6 rocprofv3 --kernel-trace --stats -d $O/trace_cfg2 -o run -- python3 /tmp/cfg2.py > $O/cfg2_under_rocprof.log 2>&1
 DB2=$(find $O/trace_cfg2 -name "*_results.db" | head -n 1)
 [ -n "$DB2" ] && python3 $R/tools/rocprof_summary.py $DB2 > $O/config2_kernel_stats.csv
 head -n 8 $O/config2_kernel_stats.csv

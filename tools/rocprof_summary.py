@@ -17,7 +17,9 @@ def main(path):
          f"from {disp} d join {sym} s on d.kernel_id = s.id group by s.kernel_name order by 3 desc")
     rows = list(cur.execute(q))
     tot = sum(r[2] for r in rows)
-    print("kernel,calls,total_ms,avg_us,min_us,max_us,pct,vgpr,agpr,sgpr,lds_bytes")
+    # (rocprofv3's arch_vgpr_count / accum_vgpr_count read HALF of the code object's register counts on this ROCm -- igemm 256x256: 128 against .vgpr_count 254,
+    #  the 4-wave loop 216 against 432, attention 104 against 207: profiles/r06_a_igemm_register_budget.txt has the real table -- hence the column names)
+    print("kernel,calls,total_ms,avg_us,min_us,max_us,pct,rocprof_arch_vgpr(=half_of_code_object),rocprof_accum_vgpr,sgpr,lds_bytes")
     for r in rows:
         print(f"\"{r[0]}\",{r[1]},{r[2]:.3f},{r[3]:.1f},{r[4]:.1f},{r[5]:.1f},{100 * r[2] / tot:.2f},{r[6]},{r[7]},{r[8]},{r[9]}")
 

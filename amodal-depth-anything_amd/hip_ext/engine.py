@@ -562,6 +562,10 @@ class Workspace:
 # fill 0.04-0.7 of a round of the 256 CUs (profiles/r05_e_config2_shapes.txt), so below HEAD_STREAMS_ROWS patch rows they are issued on four HIP streams
 # (fork / join with events: capturable into the forward's graph) and the coarse levels run in the CUs the fine level leaves idle.  Same kernels, same
 # arguments, same bits.  ADA_HEAD_STREAMS=0 / 1: never / always.
+# _second_rung_first: relative guard band around the ladder's thresholds inside which the first rung's own r decides (the rungs' maps differ by ~1e-3 of their logits)
+LADDER_GUARD = float(os.environ.get("ADA_LADDER_GUARD", "0.02"))
+# ADA_LADDER_STICKY=0: always run the first rung's head first (A/B)
+LADDER_STICKY = os.environ.get("ADA_LADDER_STICKY", "1") != "0"
 HEAD_STREAMS = os.environ.get("ADA_HEAD_STREAMS", "auto")
 HEAD_STREAMS_ROWS = int(os.environ.get("ADA_HEAD_STREAMS_ROWS", str(12 * 1369)))
 GRAPH_MODE = os.environ.get("ADA_GRAPH", "auto")
@@ -628,6 +632,8 @@ class DepthEngine:
         # Heads without a sigmoid keep the third rung's token-diversity trigger only: dict(div=..., make3=...) (DA2/dpt.py::_flat_input_rung).
         self.ladder = ladder
         self._warned = False          # the one-time notice that images are being re-run
+        self.second_rung_first_calls = 0     # calls that ran the second rung's head first (diagnostic)
+        self._start_rung = 1          # which head runs first (_run_ladder): 2 after a call most of whose images left the first rung
         if self.ladder is not None and "make" in self.ladder and not weights.tap_split and "proj" not in weights.split:
             raise HipExtError("precision ladder: the engine's weights must be packed with tap_split=True")
         self._w_hi: Optional[PackedWeights] = None
@@ -739,7 +745,7 @@ class DepthEngine:
         use = mode == "1" or (mode == "auto" and self.w.encoder in GRAPH_AUTO_ENCODERS and x.shape[0] * x.shape[-2] * x.shape[-1] <= GRAPH_AUTO_PIXELS)
         # replay bypasses the Python wrappers: with a KernelTimer or a tile log attached the launches must be issued one by one
         if not use or instrumented() or torch.cuda.is_current_stream_capturing():
-            return self._escalate(None, self._forward(x, guide, norm), x, guide, norm)
+            return self._run_ladder(x, guide, norm)
         # the kernel variant / tile override / fused-tail switch in force at capture time are baked into the graph
         key = (tuple(x.shape), None if guide is None else tuple(guide.shape), str(x.device), debug_epoch(), FUSED_TAIL, SUBPIXEL, OC1_COMMUTE, norm)
         with self._lock:
@@ -762,7 +768,7 @@ class DepthEngine:
                 while len(self._graphs) > max(1, MAX_GRAPHS):
                     self._graphs.popitem(last=False)
         if g is False:
-            return self._escalate(None, self._forward(x, guide, norm), x, guide, norm)
+            return self._run_ladder(x, guide, norm)
         return g(x, guide, (lambda ws_, out_, x_, g_: self._escalate(ws_, out_, x_, g_, norm)) if self.ladder is not None else None)
 
     def _escalate(self, ws: Optional[Workspace], out: torch.Tensor, x: Optional[torch.Tensor] = None, guide: Optional[torch.Tensor] = None,
@@ -844,43 +850,141 @@ class DepthEngine:
             self.escalated += int(idx3.numel())
             self.escalated3 += int(idx3.numel())
         idx = torch.nonzero(trigger & ~top).flatten()
+        self._start_rung = 2 if ("make" in lad and 2 * int((trigger & ~top).sum()) > B) else 1      # (third-rung images gain nothing from either head order)
         if idx.numel() == 0:
             return out
         if self._w_hi is None:
             self._w_hi = lad["make"]()
         Be = int(idx.numel())
-        key = (Be, H, W, str(out.device))
+        hi = self._head_for(ws, B, None if Be == B else idx, self._w_hi)
+        if Be == B:
+            out = hi
+        else:
+            out.index_copy_(0, idx.to(out.device), hi)
+        self.escalated += Be
+        return out
+
+    def _head_for(self, ws: Workspace, B: int, idx: Optional[torch.Tensor], w: PackedWeights) -> torch.Tensor:
+        """The DPT head with the weights ``w`` (this engine's own = first rung, or the second rung's) for the images ``idx`` (CPU index tensor; None = all B) of the
+        taps in ``ws``, on a head-only workspace of its own (cached per shape)."""
+        if idx is None and w is self.w:
+            return self._head(ws, B)
+        Be = B if idx is None else int(idx.numel())
+        dev = ws.taps[0].device
+        key = (w is self.w, Be, ws.H, ws.W, str(dev))
         ws2 = self._ws_hi.get(key)
         if ws2 is None:
             while len(self._ws_hi) >= max(1, MAX_WORKSPACES):
                 self._ws_hi.popitem(last=False)
-            ws2 = Workspace(self._w_hi, Be, H, W, out.device, head_only=True)
+            ws2 = Workspace(w, Be, ws.H, ws.W, dev, head_only=True)
             self._ws_hi[key] = ws2
         else:
             self._ws_hi.move_to_end(key)
         own = ws2.taps
         own_cls = getattr(ws2, "cls_op", None)      # use_clstoken models: the read-out also reads the final-LayerNorm'd class tokens of the first rung (ADVICE r5)
         try:
-            if Be == B:
-                ws2.taps = ws.taps        # every image of the batch: the head reads the first rung's taps in place
+            if idx is None:
+                ws2.taps = ws.taps        # every image of the batch: the head reads the encoder's taps in place
                 if own_cls is not None:
                     ws2.cls_op = ws.cls_op
             else:
-                sel = idx.to(out.device)
+                sel = idx.to(dev)
                 for t in range(4):
                     torch.index_select(ws.taps[t].view(B, -1), 0, sel, out=own[t].view(Be, -1))
                     if own_cls is not None:
                         torch.index_select(ws.cls_op[t], 0, sel, out=own_cls[t])
-            hi = self._head(ws2, Be, self._w_hi)
+            return self._head(ws2, Be, w)
         finally:
             ws2.taps = own
             if own_cls is not None:
                 ws2.cls_op = own_cls
-        if Be == B:
-            out = hi
-        else:
-            out.index_copy_(0, idx.to(out.device), hi)
-        self.escalated += Be
+
+    def _run_ladder(self, x: torch.Tensor, guide: Optional[torch.Tensor], norm: Optional[bool]) -> torch.Tensor:
+        """First rung + the ladder's check -- or, when most images of this engine's PREVIOUS call left the first rung (maps near 0: a stream of such images pays
+        12 ms of first-rung head per bs=32 step for nothing), the second rung first (_second_rung_first).  Which head runs first changes what a call costs, never
+        what it returns: every image carries exactly the output of the rung the first-rung-first order assigns it."""
+        lad = self.ladder
+        if lad is None or "make" not in lad or self._start_rung != 2 or not LADDER_STICKY or torch.cuda.is_current_stream_capturing():
+            return self._escalate(None, self._forward(x, guide, norm), x, guide, norm)
+        return self._second_rung_first(x, guide, norm)
+
+    def _ratio_of(self, out: torch.Tensor) -> torch.Tensor:
+        """r of every image of ``out`` (see _escalate) -- one reduction + one host read."""
+        sums = torch.empty(out.shape[0], STAT_CHUNKS, 2, dtype=torch.float32, device=out.device)
+        k_depth_stats(out, sums, self.final_act)
+        st = sums.cpu().double().sum(1)
+        return st[:, 1] / st[:, 0].clamp_min(1e-300)
+
+    def _second_rung_first(self, x: torch.Tensor, guide: Optional[torch.Tensor], norm: Optional[bool]) -> torch.Tensor:
+        """Encoder -> SECOND-rung head for the whole batch -> r from its output.  The two rungs' maps differ by ~1e-3 of their logits, so r2 decides for every image
+        that is not within LADDER_GUARD of a threshold: r2 > r (1 + g) keeps the second rung's result (what the first-rung-first order would have computed for it,
+        bit for bit -- the same head over the same taps), r2 > r3 (1 + g) or a flat input goes to the third rung.  Every other image -- below the threshold, or inside a
+        guard band -- gets the FIRST-rung head run for it and is decided by its r1 exactly as _escalate decides: the output is a pure function of the image either way."""
+        lad = self.ladder
+        ws = self._forward(x, guide, norm, head=False)
+        B, H, W = ws.B, ws.H, ws.W
+        D = self.w.dim
+        if self._w_hi is None:
+            self._w_hi = lad["make"]()
+        out = self._head_for(ws, B, None, self._w_hi)
+        has_div = lad.get("div", 0.0) > 0.0
+        k_depth_stats(out, ws.stat_sums, self.final_act)
+        if has_div:
+            k_token_diversity(ws.taps[3], ws.taps[3].shape[1], B, ws.ph * ws.pw, D, ws.stat_div)
+        if ws.stat_in is not None:
+            k_token_diversity(ws.a_pe, ws.a_pe.shape[1], B, ws.ph * ws.pw, self.w.pe_seg, ws.stat_in)
+        host = ws.stat_buf.cpu().double()
+        nst, ndv = B * STAT_CHUNKS * 2, B * ((D + 63) // 64) * 2
+        st, dv = host[:nst].view(B, STAT_CHUNKS, 2).sum(1), host[nst:nst + ndv].view(B, -1, 2).sum(1)
+        r2 = st[:, 1] / st[:, 0].clamp_min(1e-300)
+        flat = torch.zeros(B, dtype=torch.bool)
+        self.last_diversity = None
+        if has_div:
+            self.last_diversity = dv[:, 0] / dv[:, 1].clamp_min(1e-300)
+            flat = self.last_diversity < lad["div"]
+        if ws.stat_in is not None:
+            di = host[nst + ndv:].view(B, -1, 2).sum(1)
+            self.last_input_diversity = di[:, 0] / di[:, 1].clamp_min(1e-300)
+            flat = flat | (self.last_input_diversity < lad.get("div_in", 1e-4))
+        g = LADDER_GUARD
+        thr, thr3 = lad["r"], lad.get("r3", float("inf"))
+        has3 = "make3" in lad
+        near3 = ((r2 / thr3 - 1.0).abs() <= g) if (has3 and thr3 < float("inf")) else torch.zeros_like(flat)
+        need1 = ~flat & ((r2 <= thr * (1.0 + g)) | near3)          # the first rung decides (and, below the threshold, IS the result)
+        rung = torch.full((B,), 2, dtype=torch.int64)
+        if has3:
+            rung[flat | (r2 > thr3 * (1.0 + g))] = 3
+        ratio = r2.clone()
+        idx1 = torch.nonzero(need1).flatten()
+        out1 = None
+        if idx1.numel() > 0:
+            out1 = self._head_for(ws, B, None if idx1.numel() == B else idx1, self.w)
+            r1 = self._ratio_of(out1)
+            ratio[idx1] = r1
+            rung[idx1] = torch.where((r1 > thr3) & has3, torch.tensor(3), torch.where(r1 > thr, torch.tensor(2), torch.tensor(1)))
+        self.last_ratio = ratio
+        sel1 = torch.nonzero(rung == 1).flatten()
+        if sel1.numel() > 0:      # the first rung's maps go where the first rung stands
+            pos = {int(v): j for j, v in enumerate(idx1.tolist())}
+            src = torch.tensor([pos[int(v)] for v in sel1.tolist()], device=out.device)
+            out.index_copy_(0, sel1.to(out.device), out1.index_select(0, src))
+        sel3 = torch.nonzero(rung == 3).flatten()
+        if sel3.numel() > 0:
+            if self._eng3 is None:
+                self._eng3 = lad["make3"]()
+            s3 = sel3.to(out.device)
+            out3 = self._eng3.forward(x.index_select(0, s3), None if guide is None else guide.index_select(0, s3), norm)
+            out.index_copy_(0, s3, out3)
+        n2 = int((rung >= 2).sum())
+        self.escalated += n2
+        self.escalated3 += int(sel3.numel())
+        self.second_rung_first_calls += 1
+        self._start_rung = 2 if 2 * int((rung == 2).sum()) > B else 1
+        if not self._warned and n2:
+            self._warned = True
+            import warnings
+            warnings.warn(f"precision ladder: {n2} of {B} image(s) on the second / third rung (r up to {float(ratio.max()):.3g} against thresholds {thr} / {lad.get('r3')}); "
+                          "counted in DepthEngine.escalated / escalated3 (this message appears once per engine)")
         return out
 
     def calibrate(self, x: torch.Tensor, guide: Optional[torch.Tensor], budget: float = 9e-4, safety: float = 1.1, flat_index: Optional[int] = None,
@@ -977,7 +1081,8 @@ class DepthEngine:
             res.update(tap_diversity_images_min=dmin, tap_diversity_flat=dflat, div=math.sqrt(dmin * dflat) if dflat < 0.25 * dmin else 0.0)
         return res
 
-    def _forward(self, x: torch.Tensor, guide: Optional[torch.Tensor], norm: Optional[bool] = None) -> torch.Tensor:
+    def _forward(self, x: torch.Tensor, guide: Optional[torch.Tensor], norm: Optional[bool] = None, head: bool = True):
+        """The first rung: encoder + DPT head -> depth map.  ``head=False``: the encoder only -- returns the Workspace holding the four taps (_second_rung_first)."""
         w = self.w
         if not x.is_cuda:
             raise HipExtError("DepthEngine.forward: input must live on a HIP device (no CPU fallback in the product path)")
@@ -1075,7 +1180,7 @@ class DepthEngine:
                     k_layernorm(ws.x, N * D, B, D, w.norm_w, w.norm_b, LN_EPS, out_op=ws.cls_op[j], ld_op=ws.cls_op[j].shape[1],
                                 split_seg=ws.tap_seg)
 
-        return self._head(ws, B)
+        return self._head(ws, B) if head else ws
 
     def _head(self, ws: Workspace, B: int, w: Optional[PackedWeights] = None) -> torch.Tensor:
         w = self.w if w is None else w

@@ -87,6 +87,8 @@ SUBPIXEL = os.environ.get("ADA_SUBPIXEL", "1") == "1"
 # -- ONE GEMM over the 148^2 grid with N = 9 * features / 2 (0.41 TFLOP at ViT-L bs = 32 instead of out_conv 0.09 + output_conv1 1.65) whose nine
 # operand-typed tap maps ada_tapsum_resize_fwd gathers (9 taps x 4 bilinear corners per output element; a tap whose position falls into the
 # zero padding drops out whole, out_conv's bias included).  The up-sampled operand map p1 is never written.  ADA_OC1_COMMUTE=0: the old path.
+SUBPIXEL_SPLIT = os.environ.get("ADA_SUBPIXEL_SPLIT", "1") != "0"           # A/B: 0 = two launches wherever a level's resize / first conv are split groups (round 5)
+OC1_COMMUTE_SPLIT = os.environ.get("ADA_OC1_COMMUTE_SPLIT", "1") != "0"     # A/B: 0 = round 5's resize -> 3x3 conv path wherever "oc1" is a split group
 STAT_CHUNKS = 8
 OC1_COMMUTE = os.environ.get("ADA_OC1_COMMUTE", "1") != "0"     # operand-typed tap maps; 0: the resize -> conv path (A/B, profiles/r04_g_*; also the path of a split-precision oc1)
 
@@ -382,7 +384,12 @@ class PackedWeights:
             from .functional import subpixel_merge
             nxt = "ip" if amodal_head else "rn"
             for i, s_ in ((0, 4), (1, 2)):
-                if f"rs{i}" in self.split or f"{nxt}{i}" in self.split:
+                # (round 6) a level whose transposed conv AND the 3x3 conv behind it are split groups with fp8 correction terms is merged too: the merged weights are
+                # packed [w_hi | w_hi8 | w_lo8] per tap and `projects[i]` writes the patch-grid tensor [hi | lo8 | hi8] (needs a channel count that is a multiple of 128)
+                both = f"rs{i}" in self.split and f"{nxt}{i}" in self.split
+                if (f"rs{i}" in self.split or f"{nxt}{i}" in self.split) and not (
+                        SUBPIXEL_SPLIT and both and f8_ok and _r64(sd[f"{h}projects.{i}.weight"].shape[0]) % 128 == 0
+                        and (self.f8_only is None or {f"rs{i}", f"{nxt}{i}"} <= self.f8_only)):
                     continue
                 if amodal_head:
                     w3_, b3_ = f32(f"{h}input_projection.{i}.0.weight"), f32(f"{h}input_projection.{i}.0.bias")
@@ -392,7 +399,8 @@ class PackedWeights:
                 ci = wm.shape[2]
                 if ci % 64:
                     wm = F.pad(wm, (0, _r64(ci) - ci))
-                self.sp[i] = dict(s=s_, w=wm.reshape(wm.shape[0], -1).to(op).contiguous(), b=bias, tapb=tapb, masks=masks,
+                wq = f8_pack(wm.reshape(wm.shape[0], -1), f"{nxt}{i}", 9) if both else wm.reshape(wm.shape[0], -1).to(op).contiguous()
+                self.sp[i] = dict(s=s_, w=wq, b=bias, tapb=tapb, masks=masks, split=both,
                                   taps_per_col=sum(bin(m).count("1") for m in masks) / float(s_ * s_))
         if amodal_head:
             self.ip_w = [conv3(f32(f"{h}input_projection.{i}.0.weight"), f"ip{i}") for i in range(4)]
@@ -418,7 +426,11 @@ class PackedWeights:
         self.oc1_w, self.oc1_b = conv3(f32(s + "output_conv1.weight"), "oc1"), f32(s + "output_conv1.bias")
         self.oc1c = None     # output_conv1 composed with refinenet1.out_conv, one 1x1 per tap: [9 * half, Fp] (+ the bias each tap map carries)
         half_ = self.features // 2
-        if OC1_COMMUTE and "oc1" not in self.split and "out0" not in self.split and half_ in (32, 64, 128):
+        # (round 6) ... ALSO when "oc1" / "out0" are split groups with fp8 correction terms: the tap-map GEMM then reads u[0] as [hi | lo8 | hi8] against the composed
+        # matrix packed [w_hi | w_hi8 | w_lo8]; the nine tap maps stay operand-typed.  The ladder's second rung (-2 ms of its 27) and the raw ViT-B / ViT-L heads.
+        split_commute = (OC1_COMMUTE_SPLIT and "oc1" in self.split and "out0" in self.split and f8_ok and self.features % 128 == 0
+                         and (self.f8_only is None or {"oc1", "out0"} <= self.f8_only))
+        if OC1_COMMUTE and (split_commute or ("oc1" not in self.split and "out0" not in self.split)) and half_ in (32, 64, 128):
             from .functional import compose_f32
             w1 = f32(s + "output_conv1.weight")                                  # [half, F, 3, 3]
             wo_ = f32(s + "refinenet1.out_conv.weight").reshape(self.features, self.features)   # [F(cm), F(ci)]
@@ -430,7 +442,12 @@ class PackedWeights:
             # separately; profiles/r04_g_output_conv1_commute.txt).  K = 2 * 256 on a GEMM that is bound by its 1.6 GB of output anyway.
             wc_ = compose_f32(wt_, wo_.t())       # the library's own GEMM in split precision (functional.compose_f32); W_t b_out is a reduction
             wc_hi = wc_.to(op)
-            self.oc1c = dict(w=torch.cat([wc_hi, (wc_ - wc_hi.float()).to(op)], dim=1).contiguous(), b=(wt_.double() * bo_.double()[None, :]).sum(1).float().contiguous())
+            tap_b = (wt_.double() * bo_.double()[None, :]).sum(1).float().contiguous()
+            if split_commute:
+                wq, word = f8_weight_split(wc_, op)
+                self.oc1c = dict(w=wq, f8=word, b=tap_b)
+            else:
+                self.oc1c = dict(w=torch.cat([wc_hi, (wc_ - wc_hi.float()).to(op)], dim=1).contiguous(), b=tap_b)
         self.oc2_w, self.oc2_b = conv3(f32(s + "output_conv2.0.weight"), "oc2"), f32(s + "output_conv2.0.bias")
         self.tail_w = f32(s + "output_conv2.2.weight").reshape(-1).contiguous()
         self.tail_b = float(f32(s + "output_conv2.2.bias").reshape(-1)[0].item())
@@ -512,7 +529,7 @@ class Workspace:
         self.ocp, self.Fp = ocp, Fp
         # levels whose resize + first 3x3 conv run as one sub-pixel convolution: `projects[i]` writes a zero-bordered patch-grid tensor tp[i]
         # (the conv's A operand); t<i> and the up-sampled map L[i] do not exist
-        self.tp = {i: z(B, ph + 2, pw + 2, ocp[i]) for i in pw_.sp}
+        self.tp = {i: z(B, ph + 2, pw + 2, (2 if pw_.sp[i].get("split") else 1) * ocp[i]) for i in pw_.sp}
         self.t0 = None if 0 in pw_.sp else z(P, mm("rs0") * ocp[0])
         self.t1 = None if 1 in pw_.sp else z(P, mm("rs1") * ocp[1])
         self.pre3 = z(B, ph + 2, pw + 2, mm("rs3") * ocp[3])
@@ -1218,7 +1235,7 @@ class DepthEngine:
                 s_ = 4 if i == 0 else 2
                 if i in w.sp:     # 1x1 project -> zero-bordered patch-grid tensor; the transposed conv runs inside the sub-pixel convolution below
                     k_igemm(M=P, N=oc[i], k_alg=D, A=taps_in[i], W=w.proj_w[i], **self._kdup(KD, w.proj_w[i], a_seg=ws.tap_seg), bias=w.proj_b[i], flags=EP_BIAS,
-                            out_op=ws.tp[i], ldo_op=ocp[i], map_op=MAP_PAD, map_h=ph, map_w=pw)
+                            out_op=ws.tp[i], ldo_op=ws.tp[i].shape[3], map_op=MAP_PAD, map_h=ph, map_w=pw, split_seg=-ocp[i] if w.sp[i].get("split") else 0)
                     return
                 t = ws.t0 if i == 0 else ws.t1
                 rs_w, rs_b = (w.rs0_w, w.rs0_b) if i == 0 else (w.rs1_w, w.rs1_b)
@@ -1319,7 +1336,11 @@ class DepthEngine:
         # ---- resize x2 -> output_conv1 (dpt.py:192-193) -> resize to (14 ph, 14 pw) -> output_conv2 (3x3, ReLU, 1x1, activation) (:194-195) ----
         if w.oc1c is not None:
             ntap = 9 * ws.half
-            k_igemm(M=rows[0], N=ntap, K=2 * Fp, a_wrap=Fp, k_alg=Fch, A=ws.u[0], lda=Fp, W=w.oc1c["w"], bias=w.oc1c["b"], flags=EP_BIAS, out_op=ws.tmaps, ldo_op=ntap)
+            if "f8" in w.oc1c:      # u[0] is [hi | lo8 | hi8] (split group "out0"): a full split product with fp8 correction terms
+                k_igemm(M=rows[0], N=ntap, K=2 * Fp, k_alg=Fch, A=ws.u[0], lda=ws.u[0].shape[1], W=w.oc1c["w"], f8_from=Fp, f8_mid=Fp + Fp // 2, f8_scales=w.oc1c["f8"],
+                        bias=w.oc1c["b"], flags=EP_BIAS, out_op=ws.tmaps, ldo_op=ntap)
+            else:
+                k_igemm(M=rows[0], N=ntap, K=2 * Fp, a_wrap=Fp, k_alg=Fch, A=ws.u[0], lda=Fp, W=w.oc1c["w"], bias=w.oc1c["b"], flags=EP_BIAS, out_op=ws.tmaps, ldo_op=ntap)
             k_tapsum_resize(ws.tmaps, ntap, B, grid[0][0], grid[0][1], g2[0], g2[1], ws.half, w.oc1_b, ws.oc1, ws.half)
         else:
             k_bilinear(ws.zf[0], Fch, B, grid[0][0], grid[0][1], g2[0], g2[1], Fch, out_op=ws.p1, ld_op=ws.p1.shape[3], map_op=MAP_PAD, split_seg=S("oc1", Fp))

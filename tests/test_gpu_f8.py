@@ -327,3 +327,43 @@ def test_swiglu_split_output_forms_and_the_w3_contraction(hip, forced_tile, cfg)
     e1 = float((single.cpu() - exact).abs().mean() / exact.abs().mean())
     print(f"w3 over the split hidden (tile {cfg}): fp8 correction terms {e8:.2e} against the exact product, single precision {e1:.2e}")
     assert e8 < 4e-5 and e8 < e1 / 4
+
+
+@pytest.mark.parametrize("cfg", [-1, 3, 4])
+@pytest.mark.parametrize("s_", [2, 4])
+def test_sub_pixel_convolution_with_f8_corrections(hip, forced_tile, cfg, s_):
+    """Round 6: the merged transposed-conv + 3x3 conv of a split-precision level (ada_igemm_args.tap_cols / tap_mask: the k-walk of an N-tile visits the union of its
+    phases' taps only) over a [hi | lo8 | hi8] patch-grid tensor against per-tap [w_hi | w_hi8 | w_lo8] weights -- the masked tap walk and the fp8 k-steps together.
+    Against conv3x3(conv_transpose(x)) in float64: the scheme's error, far below single fp16 operands'."""
+    from hip_ext import engine as eng
+    from hip_ext.functional import subpixel_merge
+    _need_f16(hip)
+    op = torch.float16
+    B, C, H, W_, Cm, Co = 2, 128, 9, 11, 32, 64
+    x = _rand(B, C, H, W_, seed=81)
+    wt = _rand(C, Cm, s_, s_, seed=82) * C ** -0.5
+    bt = _rand(Cm, seed=83) * 0.1
+    w3 = _rand(Co, Cm, 3, 3, seed=84) * (9 * Cm) ** -0.5
+    b3 = _rand(Co, seed=85) * 0.1
+    wm, bias, tapb, masks = subpixel_merge(wt.to(DEV), bt.to(DEV), w3.to(DEV), b3.to(DEV), s_)
+    wq, word = eng.f8_weight_split(wm.reshape(wm.shape[0], -1), op, taps=9)
+    xin = torch.zeros(B, H + 2, W_ + 2, 2 * C, dtype=op)
+    xin[:, 1:-1, 1:-1] = _a_f8(x.permute(0, 2, 3, 1).contiguous(), op)[0]
+    ncol = s_ * s_ * Co
+    of = torch.zeros(B * H * W_, ncol, device=DEV)
+    if cfg >= 0:
+        forced_tile(cfg, 0)
+    hip.igemm(M=B * H * W_, N=ncol, K=18 * C, A=xin.to(DEV), lda=2 * C, W=wq, a_mode=hip.A_CONV3, conv=(H, W_, H + 2, W_ + 2, 1), bias=bias, flags=hip.EP_BIAS,
+              out_f32=of, ldo_f32=ncol, tap_cols=Co, tap_mask=masks, f8_from=C, f8_mid=C + C // 2, f8_scales=word)
+    # reference: the fine map, then the 3x3 conv over it with zero padding -- the merged conv adds the transposed conv's bias under every tap, also those that fall into the
+    # padding of the fine grid (the LayerNorm behind it takes them out through `tapb`): compare on the interior phases' pixels, where no tap is padded
+    fine = F.conv_transpose2d(x.double(), wt.double(), bt.double(), stride=s_)
+    ref = F.conv2d(fine, w3.double(), b3.double(), padding=1)                    # [B, Co, s H, s W]
+    got = of.cpu().double().reshape(B, H, W_, s_, s_, Co).permute(0, 5, 1, 3, 2, 4).reshape(B, Co, s_ * H, s_ * W_)
+    inner = (slice(None), slice(None), slice(1, s_ * H - 1), slice(1, s_ * W_ - 1))
+    e_f8 = float((got[inner] - ref[inner]).abs().mean() / ref[inner].abs().mean())
+    fine1 = F.conv_transpose2d(x.to(op).double(), wt.to(op).double(), bt.double(), stride=s_)
+    single = F.conv2d(fine1.to(op).double(), w3.to(op).double(), b3.double(), padding=1)
+    e_single = float((single[inner] - ref[inner]).abs().mean() / ref[inner].abs().mean())
+    print(f"sub-pixel convolution s={s_} with fp8 corrections, tile {cfg}: rel-L1 {e_f8:.2e} (two single-precision launches {e_single:.2e})")
+    assert e_f8 < 5e-5 and e_f8 < e_single / 5

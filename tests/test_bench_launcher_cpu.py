@@ -27,6 +27,8 @@ def test_bench_gpus2_launches_its_own_ranks():
     # per-rank times of the headline block: the value is computed from the slowest rank, the spread shows a straggler
     assert len(line["ms_per_step_ranks"]) == 2 and abs(max(line["ms_per_step_ranks"]) - line["ms_per_step"]) < 1e-6
     assert 0.0 <= line["rank_spread_pct"] < 100.0 and line["cpu_baseline"] is None and "N = 1" in line["cpu_baseline_note"]
+    # every rank's count of re-run images and its largest r reach rank 0 through the group (round 6; the stub's stand-in values: rank, 0.25 + 0.01 rank)
+    assert line["escalated_ranks"] == [0, 1] and [round(v, 2) for v in line["r_max_ranks"]] == [0.25, 0.26]
     assert len(r.stdout.strip().splitlines()) == 1, "only rank 0's JSON line may reach stdout"
 
 

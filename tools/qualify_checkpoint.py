@@ -65,6 +65,10 @@ def main():
     bias_key = ("" if a.raw else "encoder.") + "depth_head.scratch.output_conv2.2.bias"
     print(f"# {('raw DepthAnythingV2' if a.raw else 'AmodalDAv2')} {a.encoder}, head activation {enc.depth_head.final_act}; weights: {src}; bar {BAR:g}")
     model = model.cuda()
+    enc._engine()       # packs the weights and -- round 6 -- calibrates the ladder's thresholds for THIS checkpoint on the device (no oracle involved)
+    cal = getattr(enc, "ladder_calibration", None)
+    if cal:
+        print("# ladder calibration (module.ladder_calibration): " + ", ".join(f"{k} {v:.4g}" if isinstance(v, float) else f"{k} {v}" for k, v in cal.items()))
     worst = {}
     for size in a.sizes.split(","):
         H, W = (int(v) for v in size.split("x"))

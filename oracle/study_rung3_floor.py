@@ -25,9 +25,11 @@ class Sel(O._Numerics):
         super().__init__(torch.float32)
         self.what, self.D, self.hidden = set(what), D, hidden
 
-    @staticmethod
-    def r(t):
-        return t.to(torch.float16).to(torch.float32)
+    DT = {"fp16": torch.float16, "bf16": torch.bfloat16}[os.environ.get("DT", "fp16")]      # DT=bf16: the same question for the operand type the north star names
+
+    @classmethod
+    def r(cls, t):
+        return t.to(cls.DT).to(torch.float32)
 
     def linear(self, x, w, b=None):
         n, k = w.shape
@@ -82,7 +84,7 @@ def main():
                 e = float((out - ref).abs().mean() / ref.abs().mean())
                 dz = float((tr2["logits"] - zr).abs().mean())
                 t3 = float((tr2["tap3"] - tr["tap3"]).abs().mean() / tr["tap3"].abs().mean())
-                print(f"  fp16 rounding of {label:72s}: output rel-L1 {e:.3e}   mean |d logit| {dz:.3e}   last tap rel-L1 {t3:.3e}")
+                print(f"  {os.environ.get('DT', 'fp16')} rounding of {label:72s}: output rel-L1 {e:.3e}   mean |d logit| {dz:.3e}   last tap rel-L1 {t3:.3e}")
 
 
 if __name__ == "__main__":

@@ -637,6 +637,61 @@ class _GraphedForward:
             return out if post is None else post(self.ws, out, x, guide)
 
 
+def ladder_curve(zk: torch.Tensor, z3: torch.Tensor, act: int):
+    """The calibration's raw material (DepthEngine.calibrate; pure torch, any device): for every image [n, ...] and every shift d of the grid, (r, e) =
+    (the image's sensitivity  sum w(z3 + d) / sum |f(z3 + d)|,  the metric  sum |f(zk + d) - f(z3 + d)| / sum |f(z3 + d)|  of rung k against the third),
+    f / w = sigmoid / s(1-s), ReLU / [z > 0], identity / 1.  Returns R, E as [n, shifts] float64 tensors."""
+    a, t = zk.flatten(1).double(), z3.flatten(1).double()
+    if act == ACT_NONE:      # a shift of bare logits changes nothing but the denominator: one point per image, e = eps r exactly
+        den = t.abs().sum(1).clamp_min(1e-300)
+        return (t.shape[1] / den).unsqueeze(1), ((a - t).abs().sum(1) / den).unsqueeze(1)
+    if act == ACT_SIGMOID:      # shifts that put the map's mean between ~0.9 and ~0.02 -- in units of the logits' own spread where that is wide, so that r reaches -> 1
+        scale = t.std(dim=1, keepdim=True).clamp_min(1.0)
+        grid = -t.median(dim=1, keepdim=True).values + scale * torch.linspace(-5.0, 2.0, 29, dtype=t.dtype, device=t.device)[None, :]
+    else:                       # ReLU: shifts that leave 97 % ... 3 % of the map positive
+        qs = torch.tensor([0.03, 0.08, 0.15, 0.25, 0.35, 0.5, 0.65, 0.75, 0.85, 0.92, 0.97], dtype=t.dtype, device=t.device)
+        grid = -torch.quantile(t, qs, dim=1).t()
+    R, Em = [], []
+    for j in range(grid.shape[1]):
+        d = grid[:, j:j + 1]
+        if act == ACT_SIGMOID:
+            fa, ft = torch.sigmoid(a + d), torch.sigmoid(t + d)
+            wsum = (ft * (1 - ft)).sum(1)
+        else:
+            fa, ft = (a + d).clamp_min(0), (t + d).clamp_min(0)
+            wsum = (ft > 0).double().sum(1)
+        den = ft.sum(1).clamp_min(1e-300)
+        R.append(wsum / den)
+        Em.append((fa - ft).abs().sum(1) / den)
+    return torch.stack(R, 1), torch.stack(Em, 1)
+
+
+def ladder_thresholds(z1: torch.Tensor, z2: Optional[torch.Tensor], z3: torch.Tensor, act: int, budget: float, safety: float, rule: str = "cross") -> dict:
+    """Thresholds of the precision ladder from the logits of the rungs on the calibration images (see DepthEngine.calibrate): per rung k the largest eps = e / r over
+    the points, the `global` threshold budget / (safety eps_max) and the `cross` threshold -- the smallest r at which a calibration point has safety * e > budget (the
+    rung's error AT the operating point where it would be left, not its worst anywhere; inf when no point exceeds the budget).  r from rung 1, r3 from rung 2 (no
+    second rung: r3 from rung 1).  A sigmoid's r lives in (0, 1): its thresholds are capped at 0.97.  Pure torch: unit-tested on the CPU."""
+    if rule not in ("cross", "global"):
+        raise HipExtError(f"ladder_thresholds: rule={rule!r} (cross | global)")
+
+    def one(zk):
+        R, Em = ladder_curve(zk, z3, act)
+        eps_max = float((Em / R.clamp_min(1e-300)).max())
+        bad = Em * safety > budget
+        return eps_max, budget / (safety * max(eps_max, 1e-30)), (float(R[bad].min()) if bool(bad.any()) else float("inf"))
+    cap = (lambda v, lo: min(max(v, lo), 0.97)) if act == ACT_SIGMOID else (lambda v, lo: max(v, lo))
+    pick = (lambda g, c: c if rule == "cross" else g)
+    e1, g1, c1 = one(z1)
+    res = dict(budget=budget, safety=safety, rule=rule, eps1=e1, r_global=g1, r_cross=c1, act={ACT_SIGMOID: "sigmoid", ACT_RELU: "relu", ACT_NONE: "none"}[act])
+    if z2 is not None:
+        e2, g2, c2 = one(z2)
+        r = cap(pick(g1, c1), 0.02)
+        res.update(eps2=e2, r3_global=g2, r3_cross=c2, r=r, r3=cap(pick(g2, c2), r))
+    else:
+        res.update(r3=cap(pick(g1, c1), 0.0))
+    return res
+
+
 class DepthEngine:
     """Runs one forward.  ``final_act``: 'sigmoid' | 'relu' | 'none'."""
 
@@ -1047,52 +1102,8 @@ class DepthEngine:
             self.final_act, eng3.final_act = keep
         use = [i for i in range(B) if i != flat_index]
         sel = torch.tensor(use, device=x.device)
-
-        def curve(zk):
-            """For every calibration image and every shift d of the grid: (r, e) = (the image's sensitivity sum w(z3 + d) / sum |f(z3 + d)|, the metric
-            sum |f(zk + d) - f(z3 + d)| / sum |f(z3 + d)| of rung k against the third) -- w: s(1-s) | [z > 0] | 1."""
-            a, t = zk.index_select(0, sel).flatten(1).double(), z3.index_select(0, sel).flatten(1).double()
-            if act == ACT_NONE:      # a shift of bare logits changes nothing but the denominator: one point per image, e = eps r exactly
-                den = t.abs().sum(1).clamp_min(1e-300)
-                return (t.shape[1] / den).unsqueeze(1), ((a - t).abs().sum(1) / den).unsqueeze(1)
-            if act == ACT_SIGMOID:      # shifts that put the map's mean between ~0.9 and ~0.02
-                grid = -t.median(dim=1, keepdim=True).values + torch.linspace(-5.0, 2.0, 29, dtype=t.dtype, device=t.device)[None, :]
-            else:                       # ReLU: shifts that leave 97 % ... 3 % of the map positive
-                qs = torch.tensor([0.03, 0.08, 0.15, 0.25, 0.35, 0.5, 0.65, 0.75, 0.85, 0.92, 0.97], dtype=t.dtype, device=t.device)
-                grid = -torch.quantile(t, qs, dim=1).t()
-            R, Em = [], []
-            for j in range(grid.shape[1]):
-                d = grid[:, j:j + 1]
-                if act == ACT_SIGMOID:
-                    fa, ft = torch.sigmoid(a + d), torch.sigmoid(t + d)
-                    wsum = (ft * (1 - ft)).sum(1)
-                else:
-                    fa, ft = (a + d).clamp_min(0), (t + d).clamp_min(0)
-                    wsum = (ft > 0).double().sum(1)
-                den = ft.sum(1).clamp_min(1e-300)
-                R.append(wsum / den)
-                Em.append((fa - ft).abs().sum(1) / den)
-            return torch.stack(R, 1), torch.stack(Em, 1)
-
-        def thresholds(zk):
-            """(largest eps = e / r over the points, the threshold of the `global` rule budget / (safety eps_max), the threshold of the `cross` rule: the smallest r
-            at which a calibration point exceeds the budget -- the rung's error AT the operating point where it would be left, not its worst anywhere)"""
-            R, Em = curve(zk)
-            eps_max = float((Em / R.clamp_min(1e-300)).max())
-            bad = Em * safety > budget
-            r_cross = float(R[bad].min()) if bool(bad.any()) else float("inf")
-            return eps_max, budget / (safety * max(eps_max, 1e-30)), r_cross
-        cap = (lambda v, lo: min(max(v, lo), 0.97)) if act == ACT_SIGMOID else (lambda v, lo: max(v, lo))      # a sigmoid's r lives in (0, 1)
-        e1, g1, c1 = thresholds(z1)
-        res = dict(budget=budget, safety=safety, rule=rule, images=len(use), size=(H, W), eps1=e1, r_global=g1, r_cross=c1,
-                   act={ACT_SIGMOID: "sigmoid", ACT_RELU: "relu", ACT_NONE: "none"}[act])
-        pick = (lambda g, c: c if rule == "cross" else g)
-        if z2 is not None:
-            e2, g2, c2 = thresholds(z2)
-            r = cap(pick(g1, c1), 0.02)
-            res.update(eps2=e2, r3_global=g2, r3_cross=c2, r=r, r3=cap(pick(g2, c2), r))
-        else:
-            res.update(r3=cap(pick(g1, c1), 0.0))
+        res = ladder_thresholds(z1.index_select(0, sel), None if z2 is None else z2.index_select(0, sel), z3.index_select(0, sel), act, budget, safety, rule)
+        res.update(images=len(use), size=(H, W))
         if flat_index is not None:
             dmin, dflat = float(tap_div[use].min()), float(tap_div[flat_index])
             res.update(tap_diversity_images_min=dmin, tap_diversity_flat=dflat, div=math.sqrt(dmin * dflat) if dflat < 0.25 * dmin else 0.0)

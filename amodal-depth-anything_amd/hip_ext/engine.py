@@ -87,7 +87,6 @@ SUBPIXEL = os.environ.get("ADA_SUBPIXEL", "1") == "1"
 # -- ONE GEMM over the 148^2 grid with N = 9 * features / 2 (0.41 TFLOP at ViT-L bs = 32 instead of out_conv 0.09 + output_conv1 1.65) whose nine
 # operand-typed tap maps ada_tapsum_resize_fwd gathers (9 taps x 4 bilinear corners per output element; a tap whose position falls into the
 # zero padding drops out whole, out_conv's bias included).  The up-sampled operand map p1 is never written.  ADA_OC1_COMMUTE=0: the old path.
-OC2_PAD128 = os.environ.get("ADA_OC2_PAD128", "1") != "0"                   # A/B: 0 = three fp16 terms for a 192-channel split output_conv2 (raw ViT-G; round 5)
 SUBPIXEL_SPLIT = os.environ.get("ADA_SUBPIXEL_SPLIT", "1") != "0"           # A/B: 0 = two launches wherever a level's resize / first conv are split groups (round 5)
 OC1_COMMUTE_SPLIT = os.environ.get("ADA_OC1_COMMUTE_SPLIT", "1") != "0"     # A/B: 0 = round 5's resize -> 3x3 conv path wherever "oc1" is a split group
 STAT_CHUNKS = 8
@@ -336,17 +335,13 @@ class PackedWeights:
             assert group not in self.f8_groups, group
             return triple(w).contiguous()
 
-        def conv3(w, group, pad128=False):  # noqa: F811  [Co, Ci, 3, 3] -> [Co, 9 * 3 * Cip]: per tap [hi | hi | lo]
+        def conv3(w, group):  # noqa: F811  [Co, Ci, 3, 3] -> [Co, 9 * 3 * Cip]: per tap [hi | hi | lo]
             if group not in self.split:
                 return conv3_1(w)
             co, ci = w.shape[:2]
             w = w.permute(0, 2, 3, 1)
             if ci % 64:
                 w = F.pad(w, (0, _r64(ci) - ci))
-            if pad128 and w.shape[-1] % 128 and w.shape[-1] >= 192 and f8_ok and (self.f8_only is None or group in self.f8_only):      # (64 -> 128 would double the main term: no gain)
-                # (round 6) a channel count that is a multiple of 64 but not of 128 -- the 192-channel output_conv2 of the raw ViT-G head -- padded with zero channels so
-                # that the correction terms can take the fp8 pipe: 9 x (256 fp16 + 256 fp8-rate) slots instead of 9 x 3 x 192 fp16 ones (-33 % of the conv's time)
-                w = F.pad(w, (0, 128 - w.shape[-1] % 128))
             if f8_ok and (self.f8_only is None or group in self.f8_only) and w.shape[-1] % 128 == 0:
                 return f8_pack(w.reshape(co, -1), group, 9)
             assert group not in self.f8_groups, group
@@ -453,9 +448,7 @@ class PackedWeights:
                 self.oc1c = dict(w=wq, f8=word, b=tap_b)
             else:
                 self.oc1c = dict(w=torch.cat([wc_hi, (wc_ - wc_hi.float()).to(op)], dim=1).contiguous(), b=tap_b)
-        self.oc2_w, self.oc2_b = conv3(f32(s + "output_conv2.0.weight"), "oc2", pad128=OC2_PAD128), f32(s + "output_conv2.0.bias")
-        # operand width of output_conv2's input rows (per segment): the padded channel count of its packed weights where they are the fp8 form
-        self.oc2_seg = (int(self.oc2_w.shape[1]) // 18) if getattr(self.oc2_w, "f8_scales", 0) else _r64(half_)
+        self.oc2_w, self.oc2_b = conv3(f32(s + "output_conv2.0.weight"), "oc2"), f32(s + "output_conv2.0.bias")
         self.tail_w = f32(s + "output_conv2.2.weight").reshape(-1).contiguous()
         self.tail_b = float(f32(s + "output_conv2.2.bias").reshape(-1)[0].item())
 
@@ -578,7 +571,7 @@ class Workspace:
         # fused tail (ada_dpt_tail_fwd): resize + output_conv2 in one kernel, the up-sampled map is never materialised.  Needs the
         # single-precision head and a channel count that is already a multiple of 64 (ViT-B / ViT-L heads)
         self.fused_tail = FUSED_TAIL and fused_tail_applies(half, self.halfp, self.g296[0], H, pw_.split)
-        self.fin = None if self.fused_tail else z(B, H + 2, W + 2, mm("oc2") * (pw_.oc2_seg if "oc2" in pw_.split else self.halfp))
+        self.fin = None if self.fused_tail else z(B, H + 2, W + 2, mm("oc2") * self.halfp)
 
 
 # Head branches on side streams (round 6): the four reassemble -> input_projection -> layerN_rn chains (DA2/dpt.py:161-187) and the
@@ -1367,7 +1360,7 @@ class DepthEngine:
         if ws.fused_tail:
             k_dpt_tail(ws.oc1, ws.half, B, g2[0], g2[1], ws.H, ws.W, ws.halfp, w.oc2_w, w.oc2_b, w.tail_w, w.tail_b, self.final_act, out)
             return out
-        k_bilinear(ws.oc1, ws.half, B, g2[0], g2[1], ws.H, ws.W, ws.half, out_op=ws.fin, ld_op=ws.fin.shape[3], map_op=MAP_PAD, split_seg=S("oc2", w.oc2_seg))
+        k_bilinear(ws.oc1, ws.half, B, g2[0], g2[1], ws.H, ws.W, ws.half, out_op=ws.fin, ld_op=ws.fin.shape[3], map_op=MAP_PAD, split_seg=S("oc2", ws.halfp))
         self._conv3(ws.fin, w.oc2_w, B * ws.H * ws.W, w.oc2_w.shape[0], (ws.H, ws.W), cin=ws.half, bias=w.oc2_b, flags=EP_BIAS | EP_TAIL,
                     out_f32=out, ldo_f32=1, tail_w=w.tail_w, tail_b=w.tail_b, tail_act=self.final_act)
         return out

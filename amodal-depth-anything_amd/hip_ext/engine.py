@@ -705,6 +705,7 @@ class DepthEngine:
         self.ladder = ladder
         self._warned = False          # the one-time notice that images are being re-run
         self.second_rung_first_calls = 0     # calls that ran the second rung's head first (diagnostic)
+        self.third_rung_first_calls = 0      # ... the third-rung engine first
         self._start_rung = 1          # which head runs first (_run_ladder): 2 after a call most of whose images left the first rung
         if self.ladder is not None and "make" in self.ladder and not weights.tap_split and "proj" not in weights.split:
             raise HipExtError("precision ladder: the engine's weights must be packed with tap_split=True")
@@ -908,6 +909,8 @@ class DepthEngine:
             warnings.warn(f"precision ladder: {int((trigger | top).sum())} of {B} image(s) re-run in split precision (second rung: head only; third: whole forward) -- "
                           f"r up to {float(ratio.max()):.3g} against thresholds {lad.get('r')} / {lad.get('r3')}; counted in DepthEngine.escalated / escalated3 "
                           "(this message appears once per engine; module.precision_ladder = False switches the ladder off)")
+        # which rung the NEXT call starts on (_run_ladder): the one most of this call's images ended on
+        self._start_rung = 3 if 2 * int(top.sum()) > B else (2 if ("make" in lad and 2 * int((trigger & ~top).sum()) > B) else 1)
         idx3 = torch.nonzero(top).flatten()
         if idx3.numel() > 0:      # third rung: the whole forward in split precision for these images, straight from the inputs
             if self._eng3 is None:
@@ -922,7 +925,6 @@ class DepthEngine:
             self.escalated += int(idx3.numel())
             self.escalated3 += int(idx3.numel())
         idx = torch.nonzero(trigger & ~top).flatten()
-        self._start_rung = 2 if ("make" in lad and 2 * int((trigger & ~top).sum()) > B) else 1      # (third-rung images gain nothing from either head order)
         if idx.numel() == 0:
             return out
         if self._w_hi is None:
@@ -976,9 +978,62 @@ class DepthEngine:
         12 ms of first-rung head per bs=32 step for nothing), the second rung first (_second_rung_first).  Which head runs first changes what a call costs, never
         what it returns: every image carries exactly the output of the rung the first-rung-first order assigns it."""
         lad = self.ladder
-        if lad is None or "make" not in lad or self._start_rung != 2 or not LADDER_STICKY or torch.cuda.is_current_stream_capturing():
+        if lad is None or not LADDER_STICKY or self._start_rung == 1 or torch.cuda.is_current_stream_capturing():
             return self._escalate(None, self._forward(x, guide, norm), x, guide, norm)
-        return self._second_rung_first(x, guide, norm)
+        if self._start_rung == 3 and "make3" in lad and lad.get("r3", float("inf")) < float("inf"):
+            return self._third_rung_first(x, guide, norm)
+        if self._start_rung == 2 and "make" in lad:
+            return self._second_rung_first(x, guide, norm)
+        return self._escalate(None, self._forward(x, guide, norm), x, guide, norm)
+
+    def _third_rung_first(self, x: torch.Tensor, guide: Optional[torch.Tensor], norm: Optional[bool]) -> torch.Tensor:
+        """Most images of the previous call ended on the THIRD rung (a checkpoint / operating point whose first rung never suffices: the bf16 build, raw maps that are
+        mostly clipped): the everything-split engine runs first for the whole batch and r is read from ITS output.  Images with r3 > threshold (1 + g), or flat
+        inputs, keep it -- exactly what the first-rung-first order returns for them; every other image goes through the ordinary order (first rung, then whatever its
+        own r1 says).  A third-rung stream costs the third rung, not the sum of the rungs in front of it."""
+        lad = self.ladder
+        if self._eng3 is None:
+            self._eng3 = lad["make3"]()
+        eng3 = self._eng3
+        out = eng3.forward(x, guide, norm)
+        B, H, W = out.shape[0], out.shape[-2], out.shape[-1]
+        ws3 = eng3.workspace(B, H, W, out.device)
+        r3v = self._ratio_of(out)
+        D = self.w.dim
+        flat = torch.zeros(B, dtype=torch.bool)
+        stat = torch.zeros(B * max((D + 63) // 64, ws3.a_pe.shape[1] // 128 + 1) * 2, dtype=torch.float32, device=out.device)
+        if lad.get("div", 0.0) > 0.0:
+            G = (D + 63) // 64
+            k_token_diversity(ws3.taps[3], ws3.taps[3].shape[1], B, ws3.ph * ws3.pw, D, stat[:B * G * 2].view(B, G, 2))
+            dv = stat[:B * G * 2].view(B, G, 2).cpu().double().sum(1)
+            self.last_diversity = dv[:, 0] / dv[:, 1].clamp_min(1e-300)
+            flat = self.last_diversity < lad["div"]
+        Gi = eng3.w.pe_seg // 64
+        k_token_diversity(ws3.a_pe, ws3.a_pe.shape[1], B, ws3.ph * ws3.pw, eng3.w.pe_seg, stat[:B * Gi * 2].view(B, Gi, 2))
+        di = stat[:B * Gi * 2].view(B, Gi, 2).cpu().double().sum(1)
+        self.last_input_diversity = di[:, 0] / di[:, 1].clamp_min(1e-300)
+        flat = flat | (self.last_input_diversity < lad.get("div_in", 1e-4))
+        sure = flat | (r3v > lad["r3"] * (1.0 + LADDER_GUARD))
+        ratio = r3v.clone()
+        n3 = int(sure.sum())
+        rest = torch.nonzero(~sure).flatten()
+        rung_rest = None
+        if rest.numel() > 0:
+            sel = rest.to(out.device)
+            xs, gs = x.index_select(0, sel), (None if guide is None else guide.index_select(0, sel))
+            e0, e3 = self.escalated, self.escalated3
+            sub = self._escalate(None, self._forward(xs, gs, norm), xs, gs, norm)
+            out.index_copy_(0, sel, sub)
+            ratio[rest] = self.last_ratio if self.last_ratio is not None else r3v[rest]
+            rung_rest = (self.escalated - e0, self.escalated3 - e3)
+        self.last_ratio = ratio
+        self.escalated += n3
+        self.escalated3 += n3
+        self.third_rung_first_calls += 1
+        on3 = n3 + (rung_rest[1] if rung_rest else 0)
+        on2 = (rung_rest[0] - rung_rest[1]) if rung_rest else 0
+        self._start_rung = 3 if 2 * on3 > B else (2 if ("make" in lad and 2 * on2 > B) else 1)
+        return out
 
     def _ratio_of(self, out: torch.Tensor) -> torch.Tensor:
         """r of every image of ``out`` (see _escalate) -- one reduction + one host read."""
@@ -1051,7 +1106,7 @@ class DepthEngine:
         self.escalated += n2
         self.escalated3 += int(sel3.numel())
         self.second_rung_first_calls += 1
-        self._start_rung = 2 if 2 * int((rung == 2).sum()) > B else 1
+        self._start_rung = 3 if 2 * int((rung == 3).sum()) > B else (2 if 2 * int((rung == 2).sum()) > B else 1)
         if not self._warned and n2:
             self._warned = True
             import warnings

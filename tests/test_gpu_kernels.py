@@ -194,7 +194,8 @@ def test_subpixel_conv_matches_conv_of_conv_transpose(hip, forced_tile, s, Ci, C
             miss = (miss_y[:, None] | miss_x[None, :]).float()                            # [sH, sW]
             t = tb[Y % s][:, X % s][:, :, :, dy, dx].permute(2, 0, 1)                     # [Co, sH, sW]
             got -= (miss[None] * t)[None]
-    _close(got, ref, 2e-3, rtol=3e-3, what="sub-pixel conv (host un-shuffle)")
+    wide = 8.0 if op == torch.bfloat16 else 1.0      # (the bf16 measurement library: eight times the operand rounding)
+    _close(got, ref, 2e-3 * wide, rtol=3e-3 * wide, what="sub-pixel conv (host un-shuffle)")
     # (b) the LayerNorm that consumes it in place: channels-first LN + ReLU into a zero-bordered operand tensor (DA2/dpt.py:153-159)
     g, beta = 1.0 + 0.1 * _rand(Co, seed=36), 0.1 * _rand(Co, seed=37)
     outp = torch.zeros(B, s * H + 2, s * W + 2, Co, dtype=op, device=DEV)
@@ -989,7 +990,8 @@ def test_dpt_tail_fused(hip, B, C, hi, wi, ho, wo, act):
     hip.igemm(M=B * ho * wo, N=32, K=9 * C, A=fin, lda=C, W=wp, a_mode=hip.A_CONV3, conv=(ho, wo, ho + 2, wo + 2, 1), bias=b.to(DEV),
               flags=hip.EP_BIAS | hip.EP_TAIL, out_f32=out2, ldo_f32=1, tail_w=tw.to(DEV), tail_b=tb, tail_act=code)
     # same arithmetic, but the interpolated operand is rounded from differently contracted fp32 expressions: a few fp16 ulps flip
-    _close(out, out2[:, 0], 6e-4, rtol=1e-3, what="fused tail vs two-launch path")
+    wide = 8.0 if _op(hip) == torch.bfloat16 else 1.0      # (the two paths round the interpolated map to the operand type at different points)
+    _close(out, out2[:, 0], 6e-4 * wide, rtol=1e-3 * wide, what="fused tail vs two-launch path")
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])

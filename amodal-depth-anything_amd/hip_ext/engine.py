@@ -99,10 +99,6 @@ OC1_COMMUTE = os.environ.get("ADA_OC1_COMMUTE", "1") != "0"     # operand-typed 
 _F8_ENV = os.environ.get("ADA_F8_CORR", "1")     # 1 | 0 | enc | head (A/B: only the encoder's split blocks / only the head's split groups)
 F8_CORR = _F8_ENV != "0"
 F8_ENC, F8_HEAD = _F8_ENV in ("1", "enc"), _F8_ENV in ("1", "head")
-# Operand types whose split products may take their correction terms on the fp8 pipe.  fp16: the residual of an operand is <= 2^-11 of it.  bf16 (the measurement library,
-# ADA_F8_BF16=1): the residual is <= 2^-8 -- e5m2 / e4m3 of it still carry it to 2^-12 ... 2^-13 of the operand, i.e. better than ONE fp16 operand, at 2x the MACs' time
-# instead of the three bf16 terms' 3x (profiles/r06_m_*).  The byte forms, the 2^10 shift and the E8M0 scales do not depend on the main term's type.
-F8_DTYPES = (torch.float16,) + ((torch.bfloat16,) if os.environ.get("ADA_F8_BF16", "0") == "1" else ())
 F8_A_SCALES = 117 | (127 << 16)     # E8M0 bytes of the activation's two byte segments: lo8 = e5m2((x - x_hi) 2^10), hi8 = e5m2(x)
 
 
@@ -199,12 +195,12 @@ class PackedWeights:
         # f8: which of the two users take it -- "both" | "enc" | "head" | "none" (the caller's precision policy, DA2/dpt.py::_f8_policy)
         if f8 not in ("both", "enc", "head", "none"):
             raise HipExtError(f"PackedWeights: f8={f8!r} (both | enc | head | none)")
-        self.f8_head = F8_HEAD and f8 in ("both", "head") and op in F8_DTYPES
+        self.f8_head = F8_HEAD and f8 in ("both", "head") and op == torch.float16
         self.f8_only = None if f8_only is None else frozenset(f8_only)      # head groups that may take it (None: every split group)
-        self.enc_f8 = F8_ENC and f8 in ("both", "enc") and self.enc_split_blocks > 0 and op in F8_DTYPES and D % 128 == 0
+        self.enc_f8 = F8_ENC and f8 in ("both", "enc") and self.enc_split_blocks > 0 and op == torch.float16 and D % 128 == 0
         # the form of the taps when they are kept split: that of their reader -- this object's own "proj" group, or (tap_f8 given) the weights of
         # the ladder's second rung, which are packed later from the same state_dict
-        self.tap_f8 = (self.f8_head if tap_f8 is None else (bool(tap_f8) and F8_HEAD and op in F8_DTYPES)) and D % 128 == 0
+        self.tap_f8 = (self.f8_head if tap_f8 is None else (bool(tap_f8) and F8_HEAD and op == torch.float16)) and D % 128 == 0
         self.dim, self.depth, self.heads, self.ffn = D, cfg["depth"], cfg["heads"], cfg["ffn"]
 
         def f32(name):

@@ -133,7 +133,7 @@ def _rung1_proj_f8():
         return False
     import torch as _torch
     from hip_ext import engine as _E, operand_dtype as _opdt
-    return _E.F8_HEAD and _opdt() in _E.F8_DTYPES
+    return _E.F8_HEAD and _opdt() == _torch.float16
 _RAW_VITG_SPLIT = ("oc1", "oc2", "out", "rn1", "rn2", "rn3", "proj", "rs1", "rs3")
 
 

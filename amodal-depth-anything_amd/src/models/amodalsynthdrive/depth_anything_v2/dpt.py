@@ -369,8 +369,6 @@ class _EngineMixin:
             object.__setattr__(self, "_engine_stamp", stamp)
             if ladder is not None:
                 self._calibrate_ladder(eng, plist, explicit_r=getattr(self, "precision_ladder", None) not in (None, True) or _os.environ.get("ADA_LADDER_R") is not None)
-        elif self.__dict__.get("_ladder_cal_pending") and self._engine_obj.ladder is not None and not torch.cuda.is_current_stream_capturing():
-            self._calibrate_ladder(self._engine_obj, plist, explicit_r=getattr(self, "precision_ladder", None) not in (None, True) or _os.environ.get("ADA_LADDER_R") is not None)
         return self._engine_obj
 
     def _calibrate_ladder(self, eng, plist, explicit_r=False):
@@ -382,14 +380,10 @@ class _EngineMixin:
         is kept; the third rung and the diversity trigger are calibrated all the same."""
         import torch as _torch
         lad = eng.ladder
-        object.__setattr__(self, "_ladder_cal_pending", False)
         if not _LADDER_CALIBRATE or "make3" not in lad or not plist[0].is_cuda:     # (CPU parameters: the forward itself refuses)
             object.__setattr__(self, "ladder_calibration", None)
             return
-        if _torch.cuda.is_current_stream_capturing():      # the calibration synchronises: it waits for the first forward outside a capture (_engine); the fallback set until then
-            object.__setattr__(self, "ladder_calibration", None)
-            object.__setattr__(self, "_ladder_cal_pending", True)
-            return
+        # (no capture case to handle: packing the weights synchronises too -- an engine cannot be BUILT inside a caller's stream capture; warm up first, as for any graph)
         skip = "depth_head.scratch.output_conv2.2.bias"
         key = tuple((v.data_ptr(), v._version) for n, v in zip(self._engine_pnames, plist) if n != skip) + (getattr(self, "f8_terms", None), _LADDER_BUDGET, _LADDER_SAFETY, _LADDER_RULE, _LADDER_CAL_SIZE)
         cal = self.__dict__.get("_ladder_cal")
